@@ -1,0 +1,88 @@
+"""ctypes binding of libali_hip.so (C ABI declared in include/ali_hip.h).
+
+The library is the product: if it cannot be loaded every GPU entry point raises
+``AliHipUnavailable`` -- there is no CPU or eager-PyTorch fallback for CUDA tensors.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libali_hip.so")
+
+
+class AliHipUnavailable(RuntimeError):
+    pass
+
+
+class AliConvGeom(Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "H", "W", "C", "P", "Q", "K", "R", "S", "stride", "pad")]
+
+
+class AliEpilogue(Structure):
+    _fields_ = [("bias", c_void_p), ("act", c_int32), ("slope", c_float), ("mask", c_void_p), ("mask_ld", c_int32),
+                ("dact_y", c_void_p), ("dact", c_int32), ("dslope", c_float)]
+
+
+ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+
+# name -> (restype, argtypes); every symbol include/ali_hip.h declares
+SIGNATURES = {
+    "ali_conv_workspace_bytes": (c_size_t, [POINTER(AliConvGeom), c_int32]),
+    "ali_conv_fwd": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue), c_void_p,
+                               c_size_t, c_void_p]),
+    "ali_conv_bwd_data": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue),
+                                    c_void_p, c_size_t, c_void_p]),
+    "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
+                                      c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "ali_pack_weights": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
+                                   c_void_p]),
+    "ali_act_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "ali_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ali_rowmask_mul": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ali_dropout_mask": (c_int32, [c_uint64, c_uint64, c_float, c_void_p, c_int64, c_void_p]),
+    "ali_bn_stats": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
+    "ali_bn_apply": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                               c_void_p]),
+    "ali_bn_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                             c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ali_bce_logits": (c_int32, [c_void_p, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "ali_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                           c_int32, c_void_p]),
+    "ali_assemble_planes": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_int32, c_void_p,
+                                      c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ali_last_error": (c_char_p, []),
+    "ali_version": (c_int32, []),
+}
+
+_lib = None
+_load_error = None
+
+
+def load():
+    """Load libali_hip.so (no GPU needed just to load and resolve symbols)."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        _load_error = f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` (hipcc, gfx950)"
+        raise AliHipUnavailable(_load_error)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        _load_error = f"cannot load {LIB_PATH}: {e}"
+        raise AliHipUnavailable(_load_error)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ali_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,362 @@
+"""Fused execution of an ``nn.Sequential`` conv stack on the HIP kernels.
+
+A stack (``Encoder.layers``, ``Generator.layers``, ``Discriminator.dx/dz/dxz``;
+reference image_scms/mnist.py:30-40,63-74,98-136) is parsed once into *stages*
+
+    [Dropout2d] [BatchNorm2d] [Dropout2d]  ->  Conv2d | ConvTranspose2d | Linear(+Unflatten)  ->  LeakyReLU | Tanh
+
+and executed as ONE autograd node: forward runs the NHWC kernels stage by stage,
+backward is hand scheduled -- the activation derivative of stage i-1 (and the
+Dropout2d mask in front of stage i) is folded into the epilogue of stage i's
+data-gradient GEMM, BatchNorm backward is fused with the LeakyReLU derivative.
+The ``nn`` modules only own the parameters (reference layouts, reference
+``state_dict`` keys); their own ``forward`` is never called on CUDA tensors.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import dropout as _dropout
+from . import ops
+from .ops import ACT_LEAKY, ACT_NONE, ACT_TANH
+
+
+def _pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class Stage:
+    __slots__ = ("kind", "mod", "act", "slope", "pre", "unflat", "index")
+
+    def __init__(self, kind, mod, pre, index):
+        self.kind, self.mod, self.pre, self.index = kind, mod, pre, index
+        self.act, self.slope, self.unflat = ACT_NONE, 0.0, None
+
+
+class PackCache:
+    """Kernel-layout copies of one parameter, refreshed when the parameter's version changes
+    (the reference layouts stay the master copies: Conv [Cout,Cin,kh,kw], ConvT [Cin,Cout,kh,kw], Linear [out,in])."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, param: torch.Tensor, builder):
+        tag = (param.data_ptr(), param._version, tuple(param.shape))
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        with torch.no_grad():
+            val = builder()
+        self.store[key] = (tag, val)
+        return val
+
+
+class ChainPlan:
+    def __init__(self, seq: nn.Sequential):
+        self.seq = seq
+        self.stages: List[Stage] = []
+        self.cache = PackCache()
+        pre = []
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            name = m.__class__.__name__
+            if isinstance(m, nn.Dropout2d) or name in ("Dropout2d", "TapedDropout2d"):
+                pre.append(("drop", float(m.p)))
+            elif isinstance(m, nn.BatchNorm2d):
+                pre.append(("bn", m))
+            elif isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+                kind = "convT" if isinstance(m, nn.ConvTranspose2d) else ("conv" if isinstance(m, nn.Conv2d)
+                                                                          else "linear")
+                st = Stage(kind, m, pre, len(self.stages))
+                pre = []
+                if kind == "linear" and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Unflatten):
+                    st.unflat = tuple(mods[i + 1].unflattened_size)
+                    i += 1
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                    st.act, st.slope = ACT_LEAKY, float(mods[i + 1].negative_slope)
+                    i += 1
+                elif i + 1 < len(mods) and isinstance(mods[i + 1], nn.Tanh):
+                    st.act = ACT_TANH
+                    i += 1
+                self.stages.append(st)
+            else:
+                raise NotImplementedError(f"ali_hip.chain: unsupported layer {name}")
+            i += 1
+        if pre:
+            raise NotImplementedError("trailing Dropout2d/BatchNorm2d without a convolution")
+        for st in self.stages:
+            kinds = [p[0] for p in st.pre]
+            if kinds not in ([], ["drop"], ["bn"], ["drop", "bn"], ["bn", "drop"]):
+                raise NotImplementedError(f"unsupported pre-op pattern {kinds}")
+
+    def params(self) -> List[torch.Tensor]:
+        out = []
+        for st in self.stages:
+            for kind, m in st.pre:
+                if kind == "bn":
+                    out += [m.weight, m.bias]
+            out.append(st.mod.weight)
+            if st.mod.bias is not None:
+                out.append(st.mod.bias)
+        return out
+
+    # ------------------------------------------------------------------ packing
+    def packed(self, st: Stage, which: str, cin_stride: int):
+        """which = 'fwd' | 'dgrad' kernel-layout weights of a stage (see include/ali_hip.h)."""
+        w = st.mod.weight
+        dev = w.device
+
+        def build():
+            if st.kind == "conv":
+                K, C, R, S = w.shape
+                T = R * S
+                if which == "fwd":      # [K][T][Cpad]
+                    dst = torch.empty(K, T, cin_stride, device=dev)
+                    return ops.pack_weights(w.detach(), dst, K, T, C, cin_stride, C * T, 1, T)
+                dst = torch.zeros(cin_stride, T, K, device=dev)   # [Cpad][T][K]; rows >= C stay zero
+                ops.pack_weights(w.detach(), dst, C, T, K, K, T, 1, C * T)
+                return dst
+            if st.kind == "convT":
+                Ci, Co, R, S = w.shape
+                T = R * S
+                if which == "fwd":      # convT forward == data-gradient GEMM: [Co][T][Ci_pad]
+                    dst = torch.empty(Co, T, cin_stride, device=dev)
+                    return ops.pack_weights(w.detach(), dst, Co, T, Ci, cin_stride, T, 1, Co * T)
+                dst = torch.empty(Ci, T, Co, device=dev)           # convT dgrad == conv forward GEMM: [Ci][T][Co]
+                return ops.pack_weights(w.detach(), dst, Ci, T, Co, Co, Co * T, 1, T)
+            # linear (+Unflatten(C,h,w)): 1x1 conv whose output channel n' = t*C + co is NHWC [B,h,w,C]
+            O, I = w.shape
+            Cc, hh, ww = st.unflat if st.unflat else (O, 1, 1)
+            T = hh * ww
+            fwd = torch.empty(T, Cc, cin_stride, device=dev)
+            ops.pack_weights(w.detach(), fwd, T, Cc, I, cin_stride, I, T * I, 1)
+            if which == "fwd":
+                return fwd.reshape(O, 1, cin_stride)
+            dst = torch.zeros(cin_stride, 1, O, device=dev)        # [I_pad][1][O] = transpose of the fwd pack
+            ops.pack_weights(fwd, dst, I, 1, O, O, 1, 0, cin_stride)
+            return dst
+
+        return self.cache.get((st.index, which, cin_stride), w, build)
+
+    def packed_bias(self, st: Stage):
+        b = st.mod.bias
+        if b is None:
+            return None
+        if st.kind != "linear" or not st.unflat:
+            return b.detach()
+        Cc, hh, ww = st.unflat
+        return self.cache.get((st.index, "bias"), b,
+                              lambda: b.detach().reshape(Cc, hh * ww).t().contiguous().reshape(-1))
+
+
+# ---------------------------------------------------------------------- shapes
+def _out_shape(st: Stage, B, H, W, C):
+    m = st.mod
+    if st.kind == "conv":
+        R, S = m.kernel_size
+        s, p = m.stride[0], m.padding[0]
+        return B, (H + 2 * p - R) // s + 1, (W + 2 * p - S) // s + 1, m.out_channels
+    if st.kind == "convT":
+        R, S = m.kernel_size
+        s, p, op = m.stride[0], m.padding[0], m.output_padding[0]
+        return B, (H - 1) * s - 2 * p + R + op, (W - 1) * s - 2 * p + S + op, m.out_channels
+    if st.unflat:
+        Cc, hh, ww = st.unflat
+        return B, hh, ww, Cc
+    return B, 1, 1, m.out_features
+
+
+def _geom(st: Stage, xin_shape, out_shape):
+    """AliConvGeom of the stage's equivalent Conv2d (ConvT: roles of x / y swapped)."""
+    B, H, W, C = xin_shape
+    _, P, Q, K = out_shape
+    m = st.mod
+    if st.kind == "conv":
+        return ops.geom(B, H, W, C, P, Q, K, m.kernel_size[0], m.kernel_size[1], m.stride[0], m.padding[0])
+    if st.kind == "convT":   # x := convT output, y := convT input
+        return ops.geom(B, P, Q, K, H, W, C, m.kernel_size[0], m.kernel_size[1], m.stride[0], m.padding[0])
+    # linear: 1x1 conv on the [B,1,1,I] map with O output channels
+    return ops.geom(B, 1, 1, C, 1, 1, P * Q * K, 1, 1, 1, 0)
+
+
+def _pad_mask(mask, cpad):
+    if mask.shape[1] == cpad:
+        return mask
+    out = torch.ones(mask.shape[0], cpad, device=mask.device)
+    out[:, :mask.shape[1]] = mask
+    return out
+
+
+class _Saved:
+    __slots__ = ("x_in", "t", "y", "mask", "bn_stats", "bn", "pattern", "geom", "in_shape", "out_shape", "training")
+
+
+def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool):
+    """x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list)."""
+    saved = []
+    cur = x
+    c_log = c_log_in
+    for st in plan.stages:
+        B, H, W, Cp = cur.shape
+        rows = H * W
+        kinds = [p[0] for p in st.pre]
+        mask = None
+        bn = None
+        for kind, arg in st.pre:
+            if kind == "drop" and training:
+                mask = _pad_mask(_dropout.next_mask(B, c_log, arg, cur.device), Cp)
+            elif kind == "bn":
+                bn = arg
+        sv = _Saved()
+        sv.x_in, sv.mask, sv.bn, sv.training = cur, mask, bn, training
+        sv.pattern = kinds
+        sv.bn_stats = None
+        t = cur
+        if bn is not None:
+            mask_in = mask if kinds == ["drop", "bn"] else None
+            mask_post = mask if kinds == ["bn", "drop"] else None
+            use_batch = training or bn.running_mean is None
+            st4 = ops.bn_stats(cur, mask_in, B, rows, Cp, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                               bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch)
+            if use_batch and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            t = ops.bn_apply(cur, st4, mask_in, mask_post, B, rows, Cp)
+            sv.bn_stats = st4
+        elif mask is not None:
+            t = ops.rowmask_mul(cur, mask, B, rows, Cp)
+        out_shape = _out_shape(st, B, H, W, Cp)
+        g = _geom(st, (B, H, W, Cp), out_shape)
+        y = torch.empty(out_shape, dtype=torch.float32, device=cur.device)
+        ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope)
+        if st.kind == "convT":
+            ops.conv_bwd_data(g, t, plan.packed(st, "fwd", Cp), y, ep)
+        else:
+            ops.conv_fwd(g, t, plan.packed(st, "fwd", Cp), y, ep)
+        sv.t, sv.y, sv.geom, sv.in_shape, sv.out_shape = t, y, g, (B, H, W, Cp), out_shape
+        if save:
+            saved.append(sv)
+        cur = y
+        c_log = out_shape[3]
+    return cur, saved
+
+
+def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True):
+    """Returns (gx or None, {param tensor id -> grad})."""
+    grads = {}
+    n = len(plan.stages)
+    last = plan.stages[-1]
+    gy = gy.contiguous()
+    g_pre = ops.act_bwd(gy, saved[-1].y, last.act, last.slope) if last.act != ACT_NONE else gy
+    gx = None
+    for i in range(n - 1, -1, -1):
+        st, sv = plan.stages[i], saved[i]
+        B, H, W, Cp = sv.in_shape
+        _, P, Q, K = sv.out_shape
+        rows_out = B * P * Q
+        m = st.mod
+        g = sv.geom
+        prev = plan.stages[i - 1] if i > 0 else None
+        c_in_log = prev.mod.out_channels if (prev is not None and prev.kind != "linear") else (
+            (prev.unflat[0] if prev.unflat else prev.mod.out_features) if prev is not None else c_log_in)
+        if need_params:
+            # ---- parameter gradients of this stage
+            if m.bias is not None:
+                if st.kind == "linear" and st.unflat:
+                    Cc, hh, ww = st.unflat
+                    db = ops.colsum(B, hh * ww * Cc, hh * ww * Cc, g_pre)
+                    grads[id(m.bias)] = db.reshape(hh * ww, Cc).t().reshape(-1)
+                else:
+                    grads[id(m.bias)] = ops.colsum(rows_out, K, K, g_pre)
+            dw = torch.empty_like(m.weight)
+            if st.kind == "conv":
+                T = m.kernel_size[0] * m.kernel_size[1]
+                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1)
+            elif st.kind == "convT":
+                T = m.kernel_size[0] * m.kernel_size[1]
+                # gathered operand = convT output-grad (channels K), dense = convT input (channels Cp)
+                ops.conv_bwd_weight(g, g_pre, sv.t, dw, K, c_in_log, K * T, T, 1)
+            else:
+                O, I = m.weight.shape
+                Cc, hh, ww = st.unflat if st.unflat else (O, 1, 1)
+                T = hh * ww
+                if T == 1:
+                    ops.conv_bwd_weight(g, sv.t, g_pre, dw, I, O, I, 1, 0)
+                else:
+                    tmp = torch.empty(O, I, device=dw.device)   # rows in n' = t*C + co order
+                    ops.conv_bwd_weight(g, sv.t, g_pre, tmp, I, O, I, 1, 0)
+                    ops.pack_weights(tmp, dw, Cc, T, I, I, I, Cc * I, 1)
+            grads[id(m.weight)] = dw
+        # ---- data gradient, folded with what sits between y_{i-1} and this conv
+        if i == 0 and not need_gx and sv.bn is None:
+            break
+        pact, pslope = (prev.act, prev.slope) if prev is not None else (ACT_NONE, 0.0)
+        gt = torch.empty(sv.in_shape, dtype=torch.float32, device=gy.device)
+        if sv.bn is None:
+            ep = ops.epilogue(mask=sv.mask, dact_y=sv.x_in if pact != ACT_NONE else None, dact=pact, dslope=pslope)
+        else:
+            ep = ops.epilogue()
+        if st.kind == "convT":
+            ops.conv_fwd(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)
+        else:
+            ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)
+        if sv.bn is not None:
+            bn = sv.bn
+            mask_in = sv.mask if sv.pattern == ["drop", "bn"] else None
+            mask_pre = sv.mask if sv.pattern == ["bn", "drop"] else None
+            use_batch = sv.training or bn.running_mean is None
+            slope = pslope if pact == ACT_LEAKY else -1.0
+            want = (i > 0) or need_gx
+            dgam, dbet, gprev = ops.bn_bwd(sv.x_in, gt, mask_in, mask_pre, sv.bn_stats, bn.weight.detach(), B, H * W,
+                                           Cp, use_batch, slope, want_gx=want)
+            if need_params:
+                grads[id(bn.weight)] = dgam
+                grads[id(bn.bias)] = dbet
+            if pact == ACT_TANH and gprev is not None:
+                gprev = ops.act_bwd(gprev, sv.x_in, ACT_TANH, 0.0)
+            gt = gprev
+        if i == 0:
+            gx = gt
+        else:
+            g_pre = gt
+    return gx, grads
+
+
+class ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan: ChainPlan, training: bool, c_log_in: int, x, *params):
+        need_grad = any(ctx.needs_input_grad[3:])
+        y, saved = chain_forward(plan, x, training, c_log_in, save=need_grad)
+        ctx.plan, ctx.saved_stages, ctx.c_log_in = plan, saved, c_log_in
+        ctx.param_ids = [id(p) for p in plan.params()]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        need_gx = ctx.needs_input_grad[3]
+        need_params = any(ctx.needs_input_grad[4:])
+        gx, grads = chain_backward(ctx.plan, ctx.saved_stages, gy, ctx.c_log_in, need_gx, need_params)
+        ctx.saved_stages = None
+        pg = tuple(grads.get(pid) if need else None for pid, need in zip(ctx.param_ids, ctx.needs_input_grad[4:]))
+        return (None, None, None, gx) + pg
+
+
+def get_plan(seq: nn.Sequential) -> ChainPlan:
+    plan = seq.__dict__.get("_ali_plan")
+    if plan is None or plan.seq is not seq:
+        plan = ChainPlan(seq)
+        seq.__dict__["_ali_plan"] = plan
+    return plan
+
+
+def run_chain(seq: nn.Sequential, x: torch.Tensor, c_log_in: Optional[int] = None) -> torch.Tensor:
+    """Execute ``seq`` on NHWC ``x`` through the HIP kernels (autograd aware)."""
+    if not x.is_cuda:
+        raise RuntimeError("ali_hip.chain.run_chain needs CUDA tensors")
+    plan = get_plan(seq)
+    x = x.contiguous()
+    if c_log_in is None:
+        c_log_in = x.shape[-1]
+    return ChainFn.apply(plan, seq.training, c_log_in, x, *plan.params())

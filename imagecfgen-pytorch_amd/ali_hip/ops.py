@@ -1,0 +1,192 @@
+"""Tensor-level wrappers over the C ABI (device pointers from ``tensor.data_ptr()``,
+stream from ``torch.cuda.current_stream()``).  PyTorch is plumbing here: memory,
+streams, autograd bookkeeping.  Every function requires CUDA fp32 contiguous
+tensors and raises otherwise -- there is no fallback path.
+"""
+import ctypes
+from ctypes import byref, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_TANH, AliConvGeom, AliEpilogue  # noqa: F401
+
+_WS = {}
+_WS_BYTES = 256 << 20
+
+
+def set_workspace_bytes(n: int):
+    global _WS_BYTES
+    _WS_BYTES = int(n)
+    _WS.clear()
+
+
+def workspace(device) -> torch.Tensor:
+    """One scratch slab per device, reused stream-ordered by every kernel."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < _WS_BYTES:
+        ws = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name="tensor"):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: need a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return c_void_p(t.data_ptr())
+
+
+def _opt(t, name="tensor"):
+    return None if t is None else _chk(t, name)
+
+
+def geom(B, H, W, C, P, Q, K, R, S, stride, pad) -> AliConvGeom:
+    return AliConvGeom(B, H, W, C, P, Q, K, R, S, stride, pad)
+
+
+def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=ACT_NONE, dslope=0.0) -> AliEpilogue:
+    ep = AliEpilogue()
+    ep.bias = _opt(bias, "bias")
+    ep.act, ep.slope = act, slope
+    ep.mask = _opt(mask, "mask")
+    ep.mask_ld = mask.shape[1] if mask is not None else 0
+    ep.dact_y = _opt(dact_y, "dact_y")
+    ep.dact, ep.dslope = dact, dslope
+    return ep
+
+
+def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
+    lib = _lib.load()
+    ws = workspace(x.device)
+    _lib.check(lib.ali_conv_fwd(byref(g), _chk(x, "x"), _chk(w_packed, "w"), _chk(y, "y"), byref(ep),
+                                c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
+    return y
+
+
+def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
+    lib = _lib.load()
+    ws = workspace(dy.device)
+    _lib.check(lib.ali_conv_bwd_data(byref(g), _chk(dy, "dy"), _chk(w_packed, "w"), _chk(dx, "dx"), byref(ep),
+                                     c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
+    return dx
+
+
+def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap):
+    lib = _lib.load()
+    ws = workspace(x.device)
+    _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
+                                       s_dc, s_gc, s_tap, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+               "ali_conv_bwd_weight")
+    return dst
+
+
+def pack_weights(src, dst, N, T, C, Cpad, s_n, s_tap, s_c):
+    lib = _lib.load()
+    _lib.check(lib.ali_pack_weights(_chk(src, "src"), _chk(dst, "dst"), N, T, C, Cpad, s_n, s_tap, s_c, _stream()),
+               "ali_pack_weights")
+    return dst
+
+
+def act_bwd(gy, y, act, slope, out=None):
+    lib = _lib.load()
+    out = torch.empty_like(gy) if out is None else out
+    _lib.check(lib.ali_act_bwd(_chk(gy, "gy"), _chk(y, "y"), _chk(out), gy.numel(), act, slope, _stream()),
+               "ali_act_bwd")
+    return out
+
+
+def colsum(x2d_rows, C, ld, x, out=None):
+    lib = _lib.load()
+    ws = workspace(x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(lib.ali_colsum(_chk(x, "x"), x2d_rows, C, ld, _chk(out), c_void_p(ws.data_ptr()), ws.numel(),
+                              _stream()), "ali_colsum")
+    return out
+
+
+def rowmask_mul(x, mask, B, rows_per_img, C, out=None):
+    lib = _lib.load()
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(lib.ali_rowmask_mul(_chk(x, "x"), _chk(mask, "mask"), _chk(out), B, rows_per_img, C, _stream()),
+               "ali_rowmask_mul")
+    return out
+
+
+def dropout_mask(seed, offset, p, B, C, device):
+    lib = _lib.load()
+    out = torch.empty(B, C, dtype=torch.float32, device=device)
+    _lib.check(lib.ali_dropout_mask(seed, offset, p, _chk(out), out.numel(), _stream()), "ali_dropout_mask")
+    return out
+
+
+def bn_stats(x, mask, B, rows_per_img, C, gamma, beta, running_mean, running_var, momentum, eps, training):
+    lib = _lib.load()
+    ws = workspace(x.device)
+    st = torch.empty(4, C, dtype=torch.float32, device=x.device)  # mean, invstd, sc, sh
+    _lib.check(lib.ali_bn_stats(_chk(x, "x"), _opt(mask), B, rows_per_img, C, _opt(gamma), _opt(beta),
+                                _opt(running_mean), _opt(running_var), momentum, eps, int(training),
+                                c_void_p(st[0].data_ptr()), c_void_p(st[1].data_ptr()), c_void_p(st[2].data_ptr()),
+                                c_void_p(st[3].data_ptr()), c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+               "ali_bn_stats")
+    return st
+
+
+def bn_apply(x, st, mask_in, mask_post, B, rows_per_img, C, out=None):
+    lib = _lib.load()
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(lib.ali_bn_apply(_chk(x, "x"), c_void_p(st[2].data_ptr()), c_void_p(st[3].data_ptr()), _opt(mask_in),
+                                _opt(mask_post), _chk(out), B, rows_per_img, C, _stream()), "ali_bn_apply")
+    return out
+
+
+def bn_bwd(x, g, mask_in, mask_pre, st, gamma, B, rows_per_img, C, batch_stats, slope, want_gx=True):
+    """returns (dgamma, dbeta, gx)."""
+    lib = _lib.load()
+    ws = workspace(x.device)
+    dg = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x) if want_gx else None
+    _lib.check(lib.ali_bn_bwd(_chk(x, "x"), _chk(g, "g"), _opt(mask_in), _opt(mask_pre), c_void_p(st[0].data_ptr()),
+                              c_void_p(st[1].data_ptr()), _opt(gamma), B, rows_per_img, C, int(batch_stats),
+                              float(slope), c_void_p(dg[0].data_ptr()), c_void_p(dg[1].data_ptr()), _opt(gx),
+                              c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_bn_bwd")
+    return dg[0], dg[1], gx
+
+
+def bce_logits(logit, target, gscale=1.0, want_grad=True):
+    """returns (out2 = [loss, mean sigmoid] device tensor, glogit or None)."""
+    lib = _lib.load()
+    B = logit.numel()
+    out2 = torch.empty(2, dtype=torch.float32, device=logit.device)
+    gl = torch.empty_like(logit) if want_grad else None
+    _lib.check(lib.ali_bce_logits(_chk(logit, "logit"), B, float(target), float(gscale), _chk(out2), _opt(gl),
+                                  _stream()), "ali_bce_logits")
+    return out2, gl
+
+
+def adam(p, g, m, v, lr, beta1, beta2, eps, step):
+    lib = _lib.load()
+    _lib.check(lib.ali_adam(_chk(p, "p"), _chk(g, "g"), _chk(m, "m"), _chk(v, "v"), p.numel(), lr, beta1, beta2, eps,
+                            step, _stream()), "ali_adam")
+
+
+def assemble_planes(X, idx, tables, cont, B, H, W, Cpad):
+    """X [B,H,W] fp32; idx [B,n_emb] int32; tables: list of [n,256] fp32; cont [B,n_cont] or None."""
+    lib = _lib.load()
+    out = torch.empty(B, H, W, Cpad, dtype=torch.float32, device=X.device)
+    n_emb = len(tables)
+    arr = (c_void_p * max(n_emb, 1))(*[t.data_ptr() for t in tables])
+    for t in tables:
+        _chk(t, "embedding table")
+    if idx is not None and not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()):
+        raise ValueError("idx must be a contiguous int32 CUDA tensor")
+    n_cont = 0 if cont is None else cont.shape[1]
+    _lib.check(lib.ali_assemble_planes(_chk(X, "X"), None if idx is None else c_void_p(idx.data_ptr()),
+                                       ctypes.cast(arr, ctypes.POINTER(c_void_p)), n_emb, _opt(cont), n_cont,
+                                       _chk(out), B, H, W, Cpad, _stream()), "ali_assemble_planes")
+    return out

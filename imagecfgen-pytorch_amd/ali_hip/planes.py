@@ -1,0 +1,63 @@
+"""Conditioning-plane assembly for Encoder / Discriminator inputs.
+
+Replaces ``Embedding -> Unflatten(1,16,16) -> Upsample(nearest) -> Tanh``, the
+``continuous_feature_map`` broadcasts and the channel concat of the reference
+(mnist.py:17-18,24-29,46-55; audio_mnist.py:178-183,203-210; esrf_acoustic.py:163-170)
+with one kernel that writes the NHWC, channel-padded conv input directly.
+Backward (tiny tensors: [B,H*W] planes -> [n,256] tables) uses index_add on the device.
+"""
+import torch
+
+from . import ops
+
+_MAPS = {}
+
+
+def _src_index(H, W, device):
+    key = (H, W, str(device))
+    m = _MAPS.get(key)
+    if m is None:
+        hh = (torch.arange(H, device=device) * 16) // H
+        ww = (torch.arange(W, device=device) * 16) // W
+        m = (hh[:, None] * 16 + ww[None, :]).reshape(-1)
+        _MAPS[key] = m
+    return m
+
+
+class PlanesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, idx, cont, cpad, *tables):
+        B, H, W = X.shape
+        tabs = [t.detach().contiguous() for t in tables]
+        out = ops.assemble_planes(X.contiguous(), idx, tabs, cont.contiguous() if cont is not None else None, B, H, W,
+                                  cpad)
+        ctx.save_for_backward(idx, out)
+        ctx.n_emb, ctx.n_cont = len(tables), (0 if cont is None else cont.shape[1])
+        ctx.table_rows = [t.shape[0] for t in tables]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, out = ctx.saved_tensors
+        B, H, W, _ = g.shape
+        gX = g[..., 0].contiguous() if ctx.needs_input_grad[0] else None
+        gcont = None
+        if ctx.n_cont and ctx.needs_input_grad[2]:
+            gcont = g[..., 1 + ctx.n_emb:1 + ctx.n_emb + ctx.n_cont].sum(dim=(1, 2))
+        gtabs = []
+        src = _src_index(H, W, g.device)
+        for j in range(ctx.n_emb):
+            if not ctx.needs_input_grad[4 + j]:
+                gtabs.append(None)
+                continue
+            plane = out[..., 1 + j].reshape(B, H * W)
+            gp = g[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)          # tanh'
+            per_sample = torch.zeros(B, 256, device=g.device).index_add_(1, src, gp)
+            gt = torch.zeros(ctx.table_rows[j], 256, device=g.device).index_add_(0, idx[:, j].long(), per_sample)
+            gtabs.append(gt)
+        return (gX, None, gcont, None) + tuple(gtabs)
+
+
+def assemble(X, idx, cont, cpad, tables):
+    """X [B,H,W]; idx int32 [B,n_emb]; cont [B,n_cont] or None; tables list of [n,256] params."""
+    return PlanesFn.apply(X, idx, cont, cpad, *tables)

@@ -1,0 +1,478 @@
+// HBM-bound pointwise / reduction kernels of the ALI step: weight re-layout,
+// activation backward, bias-gradient column sums, Dropout2d masks, BatchNorm2d
+// (training + eval, forward + backward), BCE-with-logits, Adam, and the
+// conditioning-plane assembly.  Reference call sites are listed per entry point
+// in include/ali_hip.h.  All reductions are deterministic (fixed partial slabs,
+// fixed summation order; no float atomics).
+#include "ali_common.h"
+
+namespace ali {
+
+constexpr int kEwBlock = 256;
+static inline int ew_grid(long long n, int per_thread = 1) {
+  long long b = (n + (long long)kEwBlock * per_thread - 1) / ((long long)kEwBlock * per_thread);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int T, int C,
+                                    int Cpad, long long s_n, long long s_tap, long long s_c) {
+  const long long total = (long long)N * T * Cpad;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += step) {
+    const int c = (int)(i % Cpad);
+    const long long nt = i / Cpad;
+    const int tp = (int)(nt % T);
+    const long long n = nt / T;
+    dst[i] = c < C ? src[n * s_n + tp * s_tap + c * s_c] : 0.f;
+  }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gpre,
+                               long long n, int act, float slope) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += step) gpre[i] = gy[i] * act_grad_from_output(y[i], act, slope);
+}
+
+// ---- column sums: stage 1 writes [nblk][C] partials, stage 2 folds them ----
+// block = 256 threads as (256/CT) row lanes x CT channel lanes, CT = min(C,256) rounded to pow2 lanes
+__global__ void colsum_partial_kernel(const float* __restrict__ x, long long rows, int C, int ld,
+                                      float* __restrict__ part) {
+  __shared__ float red[kEwBlock];
+  const int t = threadIdx.x;
+  for (int c0 = 0; c0 < C; c0 += kEwBlock) {
+    const int cw = min(C - c0, kEwBlock);         // channels handled this sweep
+    int lanes_c = 1;
+    while (lanes_c < cw) lanes_c <<= 1;           // pow2 >= cw, <= 256
+    const int lanes_r = kEwBlock / lanes_c;
+    const int tc = t % lanes_c, tr = t / lanes_c;
+    float s = 0.f;
+    if (tc < cw)
+      for (long long r = (long long)blockIdx.x * lanes_r + tr; r < rows; r += (long long)gridDim.x * lanes_r)
+        s += x[r * ld + c0 + tc];
+    red[t] = s;
+    __syncthreads();
+    for (int off = lanes_r / 2; off > 0; off >>= 1) {
+      if (tr < off) red[t] += red[t + off * lanes_c];
+      __syncthreads();
+    }
+    if (tr == 0 && tc < cw) part[(long long)blockIdx.x * C + c0 + tc] = red[t];
+    __syncthreads();
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * C + c];
+  out[c] = (float)s;
+}
+
+__global__ void rowmask_mul_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                   float* __restrict__ out, long long n, int rows_per_img, int C) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  const long long per_img = (long long)rows_per_img * C;
+  for (; i < n; i += step) {
+    const long long img = i / per_img;
+    out[i] = x[i] * mask[img * C + (int)(i % C)];
+  }
+}
+
+// splitmix64-based counter RNG: one draw per (seed, offset + i)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void dropout_mask_kernel(uint64_t seed, uint64_t offset, float p, float* __restrict__ out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  const float keep = 1.f - p, inv = 1.f / (1.f - p);
+  for (; i < n; i += step) {
+    const uint64_t r = mix64(mix64(seed) ^ (offset + (uint64_t)i));
+    const float u = (float)(r >> 40) * (1.f / 16777216.f);
+    out[i] = u < keep ? inv : 0.f;
+  }
+}
+
+// ---- BatchNorm2d ------------------------------------------------------------
+// stage 1: per-block partial (sum, sumsq) of x~ = x*mask per channel -> part[nblk][2][C]
+__global__ void bn_stats_partial_kernel(const float* __restrict__ x, const float* __restrict__ mask, long long rows,
+                                        int rows_per_img, int C, float* __restrict__ part) {
+  __shared__ float red1[kEwBlock], red2[kEwBlock];
+  const int t = threadIdx.x;
+  int lanes_c = 1;
+  while (lanes_c < C) lanes_c <<= 1;
+  const int lanes_r = kEwBlock / lanes_c;  // C <= 256 enforced by the host
+  const int tc = t % lanes_c, tr = t / lanes_c;
+  float s1 = 0.f, s2 = 0.f;
+  if (tc < C)
+    for (long long r = (long long)blockIdx.x * lanes_r + tr; r < rows; r += (long long)gridDim.x * lanes_r) {
+      float v = x[r * C + tc];
+      if (mask) v *= mask[(r / rows_per_img) * C + tc];
+      s1 += v;
+      s2 += v * v;
+    }
+  red1[t] = s1;
+  red2[t] = s2;
+  __syncthreads();
+  for (int off = lanes_r / 2; off > 0; off >>= 1) {
+    if (tr < off) {
+      red1[t] += red1[t + off * lanes_c];
+      red2[t] += red2[t + off * lanes_c];
+    }
+    __syncthreads();
+  }
+  if (tr == 0 && tc < C) {
+    part[((long long)blockIdx.x * 2 + 0) * C + tc] = red1[t];
+    part[((long long)blockIdx.x * 2 + 1) * C + tc] = red2[t];
+  }
+}
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblk, int C, long long count,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                      float momentum, float eps, int training, float* __restrict__ mean_out,
+                                      float* __restrict__ invstd_out, float* __restrict__ sc, float* __restrict__ sh) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s1 += (double)part[((long long)b * 2 + 0) * C + c];
+      s2 += (double)part[((long long)b * 2 + 1) * C + c];
+    }
+    const double m = s1 / (double)count;
+    double v = s2 / (double)count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (running_mean) {
+      const double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = 1.f / sqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_out[c] = mean;
+  invstd_out[c] = invstd;
+  sc[c] = g * invstd;
+  sh[c] = b - mean * g * invstd;
+}
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                                const float* __restrict__ mask_in, const float* __restrict__ mask_post,
+                                float* __restrict__ out, long long n, int rows_per_img, int C) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  const long long per_img = (long long)rows_per_img * C;
+  for (; i < n; i += step) {
+    const int c = (int)(i % C);
+    const long long img = i / per_img;
+    float v = x[i];
+    if (mask_in) v *= mask_in[img * C + c];
+    v = v * sc[c] + sh[c];
+    if (mask_post) v *= mask_post[img * C + c];
+    out[i] = v;
+  }
+}
+// backward stage 1: part[nblk][2][C] = (sum g~*xhat, sum g~)
+__global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                      const float* __restrict__ mask_in, const float* __restrict__ mask_pre,
+                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      long long rows, int rows_per_img, int C, float* __restrict__ part) {
+  __shared__ float red1[kEwBlock], red2[kEwBlock];
+  const int t = threadIdx.x;
+  int lanes_c = 1;
+  while (lanes_c < C) lanes_c <<= 1;
+  const int lanes_r = kEwBlock / lanes_c;
+  const int tc = t % lanes_c, tr = t / lanes_c;
+  float s1 = 0.f, s2 = 0.f;
+  if (tc < C) {
+    const float mu = mean[tc], is = invstd[tc];
+    for (long long r = (long long)blockIdx.x * lanes_r + tr; r < rows; r += (long long)gridDim.x * lanes_r) {
+      const long long img = r / rows_per_img;
+      float xv = x[r * C + tc];
+      if (mask_in) xv *= mask_in[img * C + tc];
+      float gv = g[r * C + tc];
+      if (mask_pre) gv *= mask_pre[img * C + tc];
+      s1 += gv * (xv - mu) * is;
+      s2 += gv;
+    }
+  }
+  red1[t] = s1;
+  red2[t] = s2;
+  __syncthreads();
+  for (int off = lanes_r / 2; off > 0; off >>= 1) {
+    if (tr < off) {
+      red1[t] += red1[t + off * lanes_c];
+      red2[t] += red2[t + off * lanes_c];
+    }
+    __syncthreads();
+  }
+  if (tr == 0 && tc < C) {
+    part[((long long)blockIdx.x * 2 + 0) * C + tc] = red1[t];
+    part[((long long)blockIdx.x * 2 + 1) * C + tc] = red2[t];
+  }
+}
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += (double)part[((long long)b * 2 + 0) * C + c];
+    s2 += (double)part[((long long)b * 2 + 1) * C + c];
+  }
+  dgamma[c] = (float)s1;
+  dbeta[c] = (float)s2;
+}
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                    const float* __restrict__ mask_in, const float* __restrict__ mask_pre,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, long long n, int rows_per_img, int C,
+                                    float inv_count, int batch_stats, float slope, float* __restrict__ gx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  const long long per_img = (long long)rows_per_img * C;
+  for (; i < n; i += step) {
+    const int c = (int)(i % C);
+    const long long img = i / per_img;
+    const float xraw = x[i];
+    float xv = xraw;
+    float mi = 1.f;
+    if (mask_in) { mi = mask_in[img * C + c]; xv *= mi; }
+    float gv = g[i];
+    if (mask_pre) gv *= mask_pre[img * C + c];
+    const float is = invstd[c];
+    const float gm = gamma ? gamma[c] : 1.f;
+    float r = gv;
+    if (batch_stats) r -= (dbeta[c] + (xv - mean[c]) * is * dgamma[c]) * inv_count;
+    r *= gm * is;
+    r *= mi;
+    if (slope >= 0.f) r *= (xraw > 0.f ? 1.f : slope);
+    gx[i] = r;
+  }
+}
+
+// ---- BCE with logits against a constant target (single block; B <= a few thousand)
+__global__ void bce_logits_kernel(const float* __restrict__ logit, int B, float target, float gscale,
+                                  float* __restrict__ out2, float* __restrict__ glogit) {
+  __shared__ double r1[kEwBlock], r2[kEwBlock];
+  const int t = threadIdx.x;
+  double l = 0.0, sg = 0.0;
+  for (int i = t; i < B; i += kEwBlock) {
+    const float x = logit[i];
+    // max(x,0) - x*t + log1p(exp(-|x|))   (torch's stable form)
+    const float loss = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
+    const float s = 1.f / (1.f + expf(-x));
+    l += (double)loss;
+    sg += (double)s;
+    if (glogit) glogit[i] = gscale * (s - target) / (float)B;
+  }
+  r1[t] = l;
+  r2[t] = sg;
+  __syncthreads();
+  for (int off = kEwBlock / 2; off > 0; off >>= 1) {
+    if (t < off) { r1[t] += r1[t + off]; r2[t] += r2[t + off]; }
+    __syncthreads();
+  }
+  if (t == 0 && out2) {
+    out2[0] = (float)(r1[0] / B);
+    out2[1] = (float)(r2[0] / B);
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2_sqrt) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  const float step_size = lr / bc1;
+  for (; i < n; i += step) {
+    const float gi = g[i];
+    const float w = 1.f - b1;                                    // exp_avg.lerp_(grad, 1-beta1): torch's two-branch lerp
+    const float mi = w < 0.5f ? m[i] + w * (gi - m[i]) : gi - (gi - m[i]) * (1.f - w);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+struct EmbPtrs { const float* t[8]; };
+__global__ void assemble_planes_kernel(const float* __restrict__ X, const int* __restrict__ idx, EmbPtrs emb, int n_emb,
+                                       const float* __restrict__ cont, int n_cont, float* __restrict__ out, int B,
+                                       int H, int W, int Cpad) {
+  const long long npix = (long long)B * H * W;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < npix; i += step) {
+    const int w = (int)(i % W);
+    const long long t2 = i / W;
+    const int h = (int)(t2 % H);
+    const int b = (int)(t2 / H);
+    // nearest: src = floor(dst * 16 / size)  (torch 'nearest', probe-verified in SURVEY.md K8)
+    const int sh = (int)(((long long)h * 16) / H), sw = (int)(((long long)w * 16) / W);
+    float* o = out + i * Cpad;
+    o[0] = X[i];
+    int c = 1;
+    for (int j = 0; j < n_emb; ++j, ++c) o[c] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + sh * 16 + sw]);
+    for (int j = 0; j < n_cont; ++j, ++c) o[c] = cont[b * n_cont + j];
+    for (; c < Cpad; ++c) o[c] = 0.f;
+  }
+}
+
+}  // namespace ali
+
+using namespace ali;
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int ali_pack_weights(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t Cpad,
+                                int64_t s_n, int64_t s_tap, int64_t s_c, ali_stream_t stream) {
+  if (!src || !dst || N <= 0 || T <= 0 || C <= 0 || Cpad < C) { set_error("ali_pack_weights: bad argument"); return ALI_ERR_BAD_ARG; }
+  const long long total = (long long)N * T * Cpad;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(kEwBlock), 0, ST(stream), src, dst, N, T, C, Cpad,
+                     (long long)s_n, (long long)s_tap, (long long)s_c);
+  return check_launch("pack_weights_kernel");
+}
+
+extern "C" int ali_act_bwd(const float* gy, const float* y, float* gpre, int64_t n, int32_t act, float slope,
+                           ali_stream_t stream) {
+  if (!gy || !y || !gpre || n < 0) { set_error("ali_act_bwd: bad argument"); return ALI_ERR_BAD_ARG; }
+  if (n == 0) return ALI_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), gy, y, gpre, (long long)n, act, slope);
+  return check_launch("act_bwd_kernel");
+}
+
+static int reduce_blocks(long long rows, int C) {
+  int lanes_c = 1;
+  const int cw = C < kEwBlock ? C : kEwBlock;
+  while (lanes_c < cw) lanes_c <<= 1;
+  const int lanes_r = kEwBlock / lanes_c;
+  long long nb = (rows + (long long)lanes_r * 8 - 1) / ((long long)lanes_r * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" int ali_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, float* out, void* ws, size_t ws_bytes,
+                          ali_stream_t stream) {
+  if (!x || !out || rows <= 0 || C <= 0 || ld < C) { set_error("ali_colsum: bad argument"); return ALI_ERR_BAD_ARG; }
+  const int nb = reduce_blocks(rows, C);
+  if (!ws || ws_bytes < (size_t)nb * C * sizeof(float)) { set_error("ali_colsum: workspace too small"); return ALI_ERR_WORKSPACE; }
+  float* part = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, (long long)rows, C, ld, part);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), part, nb, C, out);
+  return check_launch("colsum");
+}
+
+extern "C" int ali_rowmask_mul(const float* x, const float* mask, float* out, int32_t B, int32_t rows_per_img,
+                               int32_t C, ali_stream_t stream) {
+  if (!x || !mask || !out || B <= 0 || rows_per_img <= 0 || C <= 0) { set_error("ali_rowmask_mul: bad argument"); return ALI_ERR_BAD_ARG; }
+  const long long n = (long long)B * rows_per_img * C;
+  hipLaunchKernelGGL(rowmask_mul_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, mask, out, n, rows_per_img, C);
+  return check_launch("rowmask_mul_kernel");
+}
+
+extern "C" int ali_dropout_mask(uint64_t seed, uint64_t offset, float p, float* out, int64_t n, ali_stream_t stream) {
+  if (!out || n <= 0 || !(p >= 0.f && p < 1.f)) { set_error("ali_dropout_mask: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), seed, offset, p, out, (long long)n);
+  return check_launch("dropout_mask_kernel");
+}
+
+extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_t rows_per_img, int32_t C,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, int32_t training, float* mean, float* invstd, float* sc,
+                            float* sh, void* ws, size_t ws_bytes, ali_stream_t stream) {
+  if (!x || B <= 0 || rows_per_img <= 0 || C <= 0 || C > kEwBlock || !mean || !invstd || !sc || !sh ||
+      (!training && (!running_mean || !running_var))) {
+    set_error("ali_bn_stats: bad argument (C must be <= 256)");
+    return ALI_ERR_BAD_ARG;
+  }
+  const long long rows = (long long)B * rows_per_img;
+  const int nb = reduce_blocks(rows, C);
+  if (!ws || ws_bytes < (size_t)nb * 2 * C * sizeof(float)) { set_error("ali_bn_stats: workspace too small"); return ALI_ERR_WORKSPACE; }
+  float* part = reinterpret_cast<float*>(ws);
+  if (training)
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, mask, rows, rows_per_img, C, part);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(256), 0, ST(stream), part, nb, C, rows, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, mean, invstd, sc, sh);
+  return check_launch("bn_stats");
+}
+
+extern "C" int ali_bn_apply(const float* x, const float* sc, const float* sh, const float* mask_in,
+                            const float* mask_post, float* out, int32_t B, int32_t rows_per_img, int32_t C,
+                            ali_stream_t stream) {
+  if (!x || !sc || !sh || !out || B <= 0 || rows_per_img <= 0 || C <= 0) { set_error("ali_bn_apply: bad argument"); return ALI_ERR_BAD_ARG; }
+  const long long n = (long long)B * rows_per_img * C;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in, mask_post, out, n,
+                     rows_per_img, C);
+  return check_launch("bn_apply_kernel");
+}
+
+extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, const float* mask_pre,
+                          const float* mean, const float* invstd, const float* gamma, int32_t B,
+                          int32_t rows_per_img, int32_t C, int32_t batch_stats, float lrelu_slope, float* dgamma,
+                          float* dbeta, float* gx, void* ws, size_t ws_bytes, ali_stream_t stream) {
+  if (!x || !g || !mean || !invstd || !dgamma || !dbeta || B <= 0 || rows_per_img <= 0 || C <= 0 || C > kEwBlock) {
+    set_error("ali_bn_bwd: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  const long long rows = (long long)B * rows_per_img;
+  const int nb = reduce_blocks(rows, C);
+  if (!ws || ws_bytes < (size_t)nb * 2 * C * sizeof(float)) { set_error("ali_bn_bwd: workspace too small"); return ALI_ERR_WORKSPACE; }
+  float* part = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean, invstd,
+                     rows, rows_per_img, C, part);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(256), 0, ST(stream), part, nb, C, dgamma, dbeta);
+  if (gx) {
+    const long long n = rows * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean,
+                       invstd, gamma, dgamma, dbeta, n, rows_per_img, C, 1.f / (float)rows, batch_stats, lrelu_slope, gx);
+  }
+  return check_launch("bn_bwd");
+}
+
+extern "C" int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, float* out2, float* glogit,
+                              ali_stream_t stream) {
+  if (!logit || B <= 0) { set_error("ali_bce_logits: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(kEwBlock), 0, ST(stream), logit, B, target, gscale, out2, glogit);
+  return check_launch("bce_logits_kernel");
+}
+
+extern "C" int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, int32_t step, ali_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) { set_error("ali_adam: bad argument"); return ALI_ERR_BAD_ARG; }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 4)), dim3(kEwBlock), 0, ST(stream), p, g, m, v, (long long)n, lr, beta1, beta2,
+                     eps, (float)bc1, (float)sqrt(bc2));
+  return check_launch("adam_kernel");
+}
+
+extern "C" int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* emb_tables, int32_t n_emb,
+                                   const float* cont, int32_t n_cont, float* out, int32_t B, int32_t H, int32_t W,
+                                   int32_t Cpad, ali_stream_t stream) {
+  if (!X || !out || B <= 0 || H <= 0 || W <= 0 || n_emb < 0 || n_emb > 8 || n_cont < 0 || 1 + n_emb + n_cont > Cpad ||
+      (n_emb > 0 && (!idx || !emb_tables)) || (n_cont > 0 && !cont)) {
+    set_error("ali_assemble_planes: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  EmbPtrs e;
+  for (int j = 0; j < 8; ++j) e.t[j] = j < n_emb ? emb_tables[j] : nullptr;
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(assemble_planes_kernel, dim3(ew_grid(npix)), dim3(kEwBlock), 0, ST(stream), X, idx, e, n_emb, cont, n_cont,
+                     out, B, H, W, Cpad);
+  return check_launch("assemble_planes_kernel");
+}

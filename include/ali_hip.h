@@ -1,0 +1,154 @@
+/*
+ * ali_hip.h -- C ABI of libali_hip.so: the MI355X (gfx950) kernels behind the
+ * ALI/BiGAN training path of wtaylor17/ImageCFGen-Pytorch (image_scms package).
+ *
+ * The reference has no FFI of its own: all of its arithmetic is dispatched by
+ * torch.nn modules.  Each entry point below names the reference call site
+ * (file:line, relative to the reference checkout) whose ATen op it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all tensors fp32 in HBM.
+ *   - activations are NHWC ([B,H,W,C], C contiguous); an op that reads an
+ *     activation with float4 loads needs its channel stride % 4 == 0 (the
+ *     callers pad 5->8 and 771->772 channels with zeros).
+ *   - every function is stream ordered, never allocates, never synchronises,
+ *     and returns 0 or a negative AliStatus; ali_last_error() gives the text.
+ *   - `ws` is caller-provided scratch (>= the matching *_workspace_bytes());
+ *     it may be reused by the next call on the same stream.
+ */
+#ifndef ALI_HIP_H
+#define ALI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ali_stream_t; /* hipStream_t */
+
+typedef enum {
+  ALI_OK = 0,
+  ALI_ERR_BAD_ARG = -1,
+  ALI_ERR_WORKSPACE = -2,
+  ALI_ERR_LAUNCH = -3
+} AliStatus;
+
+typedef enum { ALI_ACT_NONE = 0, ALI_ACT_LEAKY = 1, ALI_ACT_TANH = 2 } AliAct;
+
+/* Geometry of one Conv2d (cross-correlation) y = conv(x, W):
+ *   x [B,H,W,C] (channel stride C, may include zero padding channels)
+ *   y [B,P,Q,K] (channel stride K)
+ *   W [K][C][R][S] logically; square stride / padding.
+ * A ConvTranspose2d (mnist.py:64-72, audio_mnist.py:216-242) is described by
+ * the Conv2d it is the data-gradient of: x := its output, y := its input. */
+typedef struct {
+  int32_t B, H, W, C;
+  int32_t P, Q, K;
+  int32_t R, S, stride, pad;
+} AliConvGeom;
+
+/* Optional fused epilogue, applied in this order to v = acc:
+ *   v += bias[n]; v = act(v); v *= mask[img*mask_ld + n]; v *= act'(dact_y)
+ * dact_y has the layout of the output; act' is evaluated on the *activated*
+ * value saved in forward (leaky: y>0 ? 1 : slope, tanh: 1-y*y).            */
+typedef struct {
+  const float* bias;   /* [N] or NULL */
+  int32_t act;         /* AliAct */
+  float slope;
+  const float* mask;   /* per (image, channel) Dropout2d mask or NULL */
+  int32_t mask_ld;
+  const float* dact_y; /* or NULL */
+  int32_t dact;        /* AliAct of the producer of dact_y */
+  float dslope;
+} AliEpilogue;
+
+/* ---- implicit-GEMM convolutions (fp32 MFMA v_mfma_f32_32x32x2_f32) -------
+ * ali_conv_fwd       : nn.Conv2d forward  (mnist.py:31-39,100-135; c2d(...) in
+ *                      audio_mnist.py:186-198 etc.) and ConvTranspose2d dgrad.
+ *                      w_kxc = packed [K][R*S][C]  (ali_pack_weights).
+ * ali_conv_bwd_data  : Conv2d data gradient and nn.ConvTranspose2d forward
+ *                      (mnist.py:64-72; ct2d(...) audio_mnist.py:228-242) and
+ *                      nn.Linear+Unflatten (audio_mnist.py:226-227) as a 4x4
+ *                      transposed conv on a 1x1 map. stride 2 is decomposed
+ *                      into sub-pixel phases (no zero insertion).
+ *                      w_cxk = packed [C][R*S][K].
+ * ali_conv_bwd_weight: weight gradient of either; dst[dc*s_dc+gc*s_gc+t*s_tap]
+ *                      with gc = channel of x (logical count Cg_log), dc =
+ *                      channel of dy (logical count Cd_log), t = r*S+s.     */
+size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which /*0 fwd,1 bwd_data,2 bwd_weight*/);
+int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w_kxc, float* y,
+                 const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
+int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w_cxk, float* dx,
+                      const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
+int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst,
+                        int32_t Cg_log, int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap,
+                        void* ws, size_t ws_bytes, ali_stream_t stream);
+
+/* dst[(n*T+t)*Cpad + c] = c < C ? src[n*s_n + t*s_tap + c*s_c] : 0.
+ * Re-lays reference-layout parameters ([Cout,Cin,kh,kw] Conv2d, [Cin,Cout,kh,kw]
+ * ConvTranspose2d, [out,in] Linear) into the kernel layouts.   */
+int ali_pack_weights(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t Cpad,
+                     int64_t s_n, int64_t s_tap, int64_t s_c, ali_stream_t stream);
+
+/* ---- pointwise / reduction kernels (HBM bound) --------------------------- */
+/* gpre = gy * act'(y)  (backward of nn.LeakyReLU / nn.Tanh, mnist.py:32-73) */
+int ali_act_bwd(const float* gy, const float* y, float* gpre, int64_t n, int32_t act, float slope,
+                ali_stream_t stream);
+/* out[c] = sum_rows x[row*ld + c]  (bias gradients). ws >= 2048*C floats.  */
+int ali_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, float* out, void* ws, size_t ws_bytes,
+               ali_stream_t stream);
+/* out = x * mask[img, c]   (nn.Dropout2d forward and backward, mnist.py:99-134) */
+int ali_rowmask_mul(const float* x, const float* mask, float* out, int32_t B, int32_t rows_per_img, int32_t C,
+                    ali_stream_t stream);
+/* counter-based Bernoulli(1-p)/(1-p) masks for production runs */
+int ali_dropout_mask(uint64_t seed, uint64_t offset, float p, float* out, int64_t n, ali_stream_t stream);
+
+/* nn.BatchNorm2d in training / eval mode (mnist.py:111,114,118,122).
+ * stats: per-channel batch mean / biased var of (mask ? x*mask : x), running
+ * stats updated with `momentum` and the unbiased variance when `training`;
+ * writes sc = gamma*invstd, sh = beta - mean*sc and mean/invstd for backward.
+ * apply: out = (x*sc + sh) * (mask_post ? mask_post[img,c] : 1).
+ * bwd_reduce: dgamma = sum g~ * xhat, dbeta = sum g~, g~ = g*(mask_pre?mask_pre:1),
+ *   xhat computed from x~ = x*(mask_in?mask_in:1).
+ * bwd_apply: gx = gamma*invstd*(g~ - dbeta/N - xhat*dgamma/N)   [batch stats]
+ *            gx = gamma*invstd*g~                               [eval]
+ *            then gx *= mask_in (if given) and *= leaky'(x) (slope >= 0 given). */
+int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_t rows_per_img, int32_t C,
+                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                 float momentum, float eps, int32_t training,
+                 float* mean, float* invstd, float* sc, float* sh, void* ws, size_t ws_bytes, ali_stream_t stream);
+int ali_bn_apply(const float* x, const float* sc, const float* sh, const float* mask_in, const float* mask_post,
+                 float* out, int32_t B, int32_t rows_per_img, int32_t C, ali_stream_t stream);
+int ali_bn_bwd(const float* x, const float* g, const float* mask_in, const float* mask_pre,
+               const float* mean, const float* invstd, const float* gamma,
+               int32_t B, int32_t rows_per_img, int32_t C, int32_t batch_stats, float lrelu_slope,
+               float* dgamma, float* dbeta, float* gx, void* ws, size_t ws_bytes, ali_stream_t stream);
+
+/* nn.BCEWithLogitsLoss (mean) against a constant target, forward + gradient,
+ * and the diagnostic sigmoid().mean() (mnist.py:181,228-248).
+ * out[0] = loss, out[1] = mean(sigmoid(logit)); glogit[i] = gscale*(sigmoid-t)/B. */
+int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, float* out2, float* glogit,
+                   ali_stream_t stream);
+
+/* torch.optim.Adam step (mnist.py:176-179,230,236,241), no amsgrad / decay.
+ * One launch over a flat parameter segment; `step` is the 1-based step count. */
+int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+             float eps, int32_t step, ali_stream_t stream);
+
+/* Conditioning-plane assembly (mnist.py:24-29,46-55; audio_mnist.py:178-209):
+ * out[b,h,w,0] = X[b,h,w]; out[..,1+j] = tanh(emb_j[idx_j[b]][src(h,w)]) for the
+ * n_emb categorical planes (16x16 tables, nearest up-sampling, src = floor(dst*16/H));
+ * then n_cont broadcast scalars cont[b,j]; remaining channels up to Cpad = 0. */
+int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* emb_tables, int32_t n_emb,
+                        const float* cont, int32_t n_cont, float* out, int32_t B, int32_t H, int32_t W,
+                        int32_t Cpad, ali_stream_t stream);
+
+const char* ali_last_error(void);
+int ali_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALI_HIP_H */

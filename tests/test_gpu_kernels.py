@@ -1,0 +1,252 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against torch-CPU fp32/fp64
+references of the same op.  Shapes: every distinct layer of the MorphoMNIST stacks
+plus the 5x5 stride-2 family of the spectrogram models and ragged / degenerate cases."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-4  # fp32 MFMA = fp32 fma chain; only the summation order differs from the CPU reference
+
+
+def _ops():
+    from ali_hip import ops
+    return ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, rtol=RTOL, what=""):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def pack_conv_fwd(ops, w, cpad):
+    K, C, R, S = w.shape
+    dst = torch.empty(K, R * S, cpad, device="cuda")
+    return ops.pack_weights(w.cuda().contiguous(), dst, K, R * S, C, cpad, C * R * S, 1, R * S)
+
+
+def pack_conv_dgrad(ops, w, cpad):
+    K, C, R, S = w.shape
+    dst = torch.zeros(cpad, R * S, K, device="cuda")
+    ops.pack_weights(w.cuda().contiguous(), dst, C, R * S, K, K, R * S, 1, C * R * S)
+    return dst
+
+
+CONV_CASES = [
+    # B, C, H, K, R, stride, pad      (mnist.py:31-39, 100-135)
+    (6, 5, 28, 64, 3, 2, 1), (6, 64, 14, 128, 4, 2, 1), (6, 128, 7, 256, 4, 2, 1), (6, 256, 3, 512, 4, 2, 1),
+    (6, 512, 1, 512, 1, 2, 0), (6, 5, 28, 32, 5, 1, 0), (6, 32, 24, 64, 4, 2, 0), (6, 64, 11, 128, 4, 1, 0),
+    (6, 128, 8, 256, 4, 2, 0), (6, 256, 3, 512, 3, 1, 0), (130, 512, 1, 512, 1, 1, 0), (130, 1024, 1, 1024, 1, 1, 0),
+    (130, 1024, 1, 1, 1, 1, 0),
+    # 5x5 stride-2 pad-1 family (audio_mnist.py:186-198), odd maps 63 -> 31 -> 15 -> 7 -> 3 -> 1
+    (2, 7, 32, 16, 5, 2, 1), (3, 16, 15, 32, 5, 2, 1), (3, 32, 7, 64, 5, 2, 1), (5, 64, 3, 128, 5, 2, 1),
+    (1, 3, 37, 8, 5, 2, 1),
+    (512, 256, 3, 512, 4, 2, 1),   # split-K path at the bench batch
+]
+
+
+@pytest.mark.parametrize("B,C,H,K,R,stride,pad", CONV_CASES)
+def test_conv2d_fwd_bwd(B, C, H, K, R, stride, pad):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + C + K)
+    x = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.conv2d(xr, wr, br, stride=stride, padding=pad), 0.2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    P = yr.shape[2]
+    cpad = (C + 3) // 4 * 4
+    xh = torch.zeros(B, H, H, cpad, device="cuda")
+    xh[..., :C] = nhwc(x).cuda()
+    geom = ops.geom(B, H, H, cpad, P, P, K, R, R, stride, pad)
+    y = torch.empty(B, P, P, K, device="cuda")
+    ops.conv_fwd(geom, xh, pack_conv_fwd(ops, w, cpad), y, ops.epilogue(bias=b.cuda(), act=ops.ACT_LEAKY, slope=0.2))
+    close(nchw(y), yr, what="fwd")
+    # backward: act', bias grad, data grad, weight grad
+    gpre = ops.act_bwd(nhwc(gy).cuda(), y, ops.ACT_LEAKY, 0.2)
+    db = ops.colsum(B * P * P, K, K, gpre)
+    close(db, br.grad, what="db")
+    dx = torch.empty(B, H, H, cpad, device="cuda")
+    ops.conv_bwd_data(geom, gpre, pack_conv_dgrad(ops, w, cpad), dx, ops.epilogue())
+    close(nchw(dx[..., :C]), xr.grad, what="dgrad")
+    if cpad != C:
+        assert dx[..., C:].abs().max().item() == 0.0
+    dw = torch.empty(K, C, R, R, device="cuda")
+    ops.conv_bwd_weight(geom, xh, gpre, dw, C, K, C * R * R, R * R, 1)
+    close(dw, wr.grad, what="wgrad")
+
+
+CONVT_CASES = [
+    # B, Cin, Hin, Cout, R, stride, pad, out_pad   (mnist.py:64-72; ct2d audio_mnist.py:228-242)
+    (6, 771, 1, 512, 3, 1, 0, 0), (6, 512, 3, 256, 3, 2, 0, 0), (6, 256, 7, 128, 3, 2, 1, 0),
+    (6, 128, 13, 64, 3, 2, 1, 0), (6, 64, 25, 1, 4, 1, 0, 0),
+    (3, 64, 4, 32, 5, 2, 2, 1), (3, 32, 8, 16, 5, 2, 2, 1), (2, 16, 16, 1, 5, 2, 2, 1), (2, 8, 5, 4, 5, 2, 2, 1),
+    (512, 771, 1, 512, 3, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("B,Ci,H,Co,R,stride,pad,opad", CONVT_CASES)
+def test_conv_transpose2d_fwd_bwd(B, Ci, H, Co, R, stride, pad, opad):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 77 + Ci + Co)
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Ci, Co, R, R, generator=g) / (Ci * R * R / stride ** 2) ** 0.5
+    b = torch.randn(Co, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.tanh(F.conv_transpose2d(xr, wr, br, stride=stride, padding=pad, output_padding=opad))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    Ho = yr.shape[2]
+    cpad = (Ci + 3) // 4 * 4
+    xh = torch.zeros(B, H, H, cpad, device="cuda")
+    xh[..., :Ci] = nhwc(x).cuda()
+    T = R * R
+    geom = ops.geom(B, Ho, Ho, Co, H, H, cpad, R, R, stride, pad)   # the conv this convT is the dgrad of
+    wf = torch.empty(Co, T, cpad, device="cuda")
+    ops.pack_weights(w.cuda().contiguous(), wf, Co, T, Ci, cpad, T, 1, Co * T)
+    y = torch.empty(B, Ho, Ho, Co, device="cuda")
+    ops.conv_bwd_data(geom, xh, wf, y, ops.epilogue(bias=b.cuda(), act=ops.ACT_TANH))
+    close(nchw(y), yr, what="convT fwd")
+    gpre = ops.act_bwd(nhwc(gy).cuda(), y, ops.ACT_TANH, 0.0)
+    close(ops.colsum(B * Ho * Ho, Co, Co, gpre), br.grad, what="db")
+    wd = torch.empty(Ci, T, Co, device="cuda")
+    ops.pack_weights(w.cuda().contiguous(), wd, Ci, T, Co, Co, Co * T, 1, T)
+    dx = torch.empty(B, H, H, Ci, device="cuda")
+    g2 = ops.geom(B, Ho, Ho, Co, H, H, Ci, R, R, stride, pad)
+    ops.conv_fwd(g2, gpre, wd, dx, ops.epilogue())
+    close(nchw(dx), xr.grad, what="convT dgrad")
+    dw = torch.empty(Ci, Co, R, R, device="cuda")
+    ops.conv_bwd_weight(geom, gpre, xh, dw, Co, Ci, Co * T, T, 1)
+    close(dw, wr.grad, what="convT wgrad")
+
+
+def test_fused_epilogue_mask_and_dact():
+    """dgrad epilogue: v *= mask[img, c]; v *= leaky'(y_prev)  (Dropout2d + LeakyReLU backward folded in)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, C, H, K, R = 9, 64, 6, 32, 3
+    w = torch.randn(K, C, R, R, generator=g) * 0.1
+    yprev = torch.randn(B, H, H, C, generator=g)
+    mask = (torch.rand(B, C, generator=g) > 0.5).float() * 2
+    gy = torch.randn(B, H - 2, H - 2, K, generator=g)
+    geom = ops.geom(B, H, H, C, H - 2, H - 2, K, R, R, 1, 0)
+    dx = torch.empty(B, H, H, C, device="cuda")
+    ops.conv_bwd_data(geom, gy.cuda(), pack_conv_dgrad(ops, w, C), dx,
+                      ops.epilogue(mask=mask.cuda(), dact_y=yprev.cuda(), dact=ops.ACT_LEAKY, dslope=0.1))
+    ref = F.conv_transpose2d(nchw(gy), w)                       # plain dgrad
+    ref = ref * mask[:, :, None, None] * torch.where(nchw(yprev) > 0, 1.0, 0.1)
+    close(nchw(dx), ref, what="fused dgrad epilogue")
+
+
+@pytest.mark.parametrize("order", ["bn_drop", "drop_bn", "bn", "eval"])
+def test_batchnorm_fwd_bwd(order):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, C, H = 7, 64, 5
+    y = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
+    mask = (torch.rand(B, C, generator=g) > 0.5).float() * 2
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    go = torch.randn(B, C, H, H, generator=g)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gam), bn.bias.copy_(bet)
+        bn.running_mean.normal_(generator=g), bn.running_var.uniform_(0.5, 2, generator=g)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train(order != "eval")
+    yr = y.clone().requires_grad_(True)
+    m4 = mask[:, :, None, None]
+    a = F.leaky_relu(yr, 0.1)                       # BN input is a LeakyReLU output in the reference stacks
+    if order == "drop_bn":
+        out = bn(a * m4)
+    elif order == "bn_drop":
+        out = bn(a) * m4
+    else:
+        out = bn(a)
+    out.backward(go)
+    ah = nhwc(a.detach()).cuda()
+    mk = mask.cuda()
+    rm, rv = rm0.clone().cuda(), rv0.clone().cuda()
+    mask_in = mk if order == "drop_bn" else None
+    mask_post = mk if order == "bn_drop" else None
+    st = ops.bn_stats(ah, mask_in, B, H * H, C, gam.cuda(), bet.cuda(), rm, rv, 0.1, 1e-5, order != "eval")
+    o = ops.bn_apply(ah, st, mask_in, mask_post, B, H * H, C)
+    close(nchw(o), out, what="bn fwd")
+    close(rm, bn.running_mean, rtol=1e-5, what="running_mean")
+    close(rv, bn.running_var, rtol=1e-5, what="running_var")
+    dgam, dbet, gx = ops.bn_bwd(ah, nhwc(go).cuda(), mask_in, mask_post, st, gam.cuda(), B, H * H, C,
+                                order != "eval", 0.1)
+    close(dgam, bn.weight.grad, what="dgamma")
+    close(dbet, bn.bias.grad, what="dbeta")
+    close(nchw(gx), yr.grad, what="bn bwd fused with leaky'")
+
+
+def test_bce_adam_colsum_dropout():
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    logit = torch.randn(512, 1, generator=g) * 3
+    for tgt in (0.0, 1.0):
+        lr_ = logit.clone().requires_grad_(True)
+        loss = F.binary_cross_entropy_with_logits(lr_, torch.full_like(lr_, tgt))
+        (0.5 * loss).backward()
+        out2, gl = ops.bce_logits(logit.cuda(), tgt, 0.5)
+        close(out2[0:1], loss.reshape(1), rtol=1e-6, what="bce")
+        close(out2[1:2], torch.sigmoid(logit).mean().reshape(1), rtol=1e-6, what="sigmoid mean")
+        close(gl, lr_.grad, rtol=1e-5, what="bce grad")
+    # Adam vs torch.optim.Adam, 3 steps, betas (0.5, 0.999) (mnist.py:176-179)
+    p = torch.randn(10007, generator=g)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([pr], lr=1e-4, betas=(0.5, 0.999))
+    pd, m, v = p.cuda(), torch.zeros(10007, device="cuda"), torch.zeros(10007, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(10007, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        ops.adam(pd, gr.cuda(), m, v, 1e-4, 0.5, 0.999, 1e-8, step)
+    assert (pd.cpu() - pr.detach()).abs().max().item() < 1e-7
+    x = torch.randn(3001, 40, generator=g)
+    close(ops.colsum(3001, 40, 40, x.cuda()), x.sum(0), rtol=1e-5, what="colsum")
+    mk = ops.dropout_mask(7, 0, 0.2, 4096, 64, torch.device("cuda"))
+    vals = torch.unique(mk).cpu()
+    assert set(np.round(vals.numpy(), 4).tolist()) == {0.0, 1.25}
+    assert abs((mk > 0).float().mean().item() - 0.8) < 0.01
+    assert not torch.equal(mk, ops.dropout_mask(7, 4096 * 64, 0.2, 4096, 64, torch.device("cuda")))
+
+
+def test_assemble_planes_matches_torch_modules():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    B = 5
+    emb = torch.nn.Embedding(10, 256)
+    seq = torch.nn.Sequential(emb, torch.nn.Unflatten(1, (1, 16, 16)), torch.nn.Upsample(size=(28, 28)),
+                              torch.nn.Tanh())
+    X = torch.randn(B, 28, 28, generator=g)
+    idx = torch.randint(0, 10, (B,), generator=g)
+    cont = torch.randn(B, 3, generator=g)
+    ref = torch.cat([X[:, None], seq(idx)] + [cont[:, j].reshape(B, 1, 1, 1).repeat(1, 1, 28, 28) for j in range(3)], 1)
+    out = ops.assemble_planes(X.cuda(), idx.to(torch.int32).reshape(B, 1).cuda(), [emb.weight.detach().cuda()],
+                              cont.cuda(), B, 28, 28, 8)
+    close(nchw(out[..., :5]), ref, rtol=1e-6, what="planes")
+    assert out[..., 5:].abs().max().item() == 0
+    # scale-factor variant (audio: 16 -> 128)
+    seq2 = torch.nn.Sequential(emb, torch.nn.Unflatten(1, (1, 16, 16)), torch.nn.Upsample(scale_factor=8),
+                               torch.nn.Tanh())
+    X2 = torch.randn(B, 128, 128, generator=g)
+    out2 = ops.assemble_planes(X2.cuda(), idx.to(torch.int32).reshape(B, 1).cuda(), [emb.weight.detach().cuda()],
+                               None, B, 128, 128, 4)
+    close(out2[..., 1], seq2(idx)[:, 0], rtol=1e-6, what="planes x8")

@@ -1,0 +1,182 @@
+"""GPU parity of the drop-in modules and of the ALI iteration against the CPU oracle
+(oracle/ali_oracle.py, itself pinned to the reference by tests/test_oracle_golden.py).
+Tolerance: BASELINE.json north_star asks 1e-3 relative on losses / reconstructions; the fp32-MFMA
+path is held to 2e-4 of each tensor's max-abs (losses 1e-5)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import ali_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def close(got, ref, rtol=TOL, what=""):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def to_dev(c):
+    return {k: v.cuda() for k, v in c.items()}
+
+
+def product_models(family):
+    if family == "mnist":
+        import image_scms.mnist as pm
+        return pm.Encoder(), pm.Generator(), pm.Discriminator()
+    raise NotImplementedError(family)
+
+
+def paired_models(family="mnist", rescale=True, d=64):
+    """oracle modules on CPU and product modules on cuda with identical weights."""
+    from test_oracle_golden import make_module_case
+    Eo, Go, Do, images, c, z = make_module_case(family, 4, d)
+    if not rescale:
+        torch.manual_seed(11)
+        Eo, Go, Do = orc.build_models(family, d)
+    E, G, D = product_models(family)
+    for src, dst in ((Eo, E), (Go, G), (Do, D)):
+        dst.load_state_dict(copy.deepcopy(src.state_dict()))
+    return (Eo, Go, Do), (E.cuda(), G.cuda(), D.cuda()), images, c, z
+
+
+def check_param_grads(mod_o, mod_p, what, rtol=TOL):
+    go = dict(mod_o.named_parameters())
+    for k, p in mod_p.named_parameters():
+        ref = go[k].grad if go[k].grad is not None else torch.zeros_like(go[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        close(got, ref, rtol, f"{what}.{k}.grad")
+
+
+def test_mnist_modules_fwd_bwd_vs_oracle():
+    import ali_hip
+    (Eo, Go, Do), (E, G, D), images, c, z = paired_models("mnist")
+    gcot = torch.Generator().manual_seed(9)
+    cd = to_dev(c)
+    # Encoder
+    Eo.train(), E.train()
+    exo = Eo(images, c)
+    w = torch.randn(exo.shape, generator=gcot)
+    (exo * w).sum().backward()
+    ex = E(images.cuda(), cd)
+    close(ex, exo, what="E.out")
+    (ex * w.cuda()).sum().backward()
+    check_param_grads(Eo, E, "E")
+    # Generator, grads w.r.t. z too
+    zo = z.clone().requires_grad_(True)
+    gzo = Go(zo, c)
+    w = torch.randn(gzo.shape, generator=gcot)
+    (gzo * w).sum().backward()
+    zp = z.clone().cuda().requires_grad_(True)
+    gz = G(zp, cd)
+    close(gz, gzo, what="G.out")
+    (gz * w.cuda()).sum().backward()
+    close(zp.grad, zo.grad, what="G.gz")
+    check_param_grads(Go, G, "G")
+    # Discriminator: eval mode, then train mode with the oracle's masks replayed
+    for mode in ("eval", "train"):
+        Do.zero_grad(), D.zero_grad()
+        Do.train(mode == "train"), D.train(mode == "train")
+        tape = orc.MaskTape()
+        xo = images.clone().requires_grad_(True)
+        zo = exo.detach().clone().requires_grad_(True)
+        torch.manual_seed(21)
+        with orc.use_tape(tape):
+            dlo = Do(xo, zo, c)
+        w = torch.randn(dlo.shape, generator=gcot)
+        (dlo * w).sum().backward()
+        xp = images.clone().cuda().requires_grad_(True)
+        zp = exo.detach().clone().cuda().requires_grad_(True)
+        with ali_hip.injected_masks(tape.masks):
+            dl = D(xp, zp, cd)
+        close(dl, dlo, what=f"D.{mode}.out")
+        (dl * w.cuda()).sum().backward()
+        close(zp.grad, zo.grad, what=f"D.{mode}.gz")
+        close(xp.grad, xo.grad, what=f"D.{mode}.gx")
+        check_param_grads(Do, D, f"D.{mode}")
+        for k, v in D.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                close(v.float(), Do.state_dict()[k].float(), 1e-5, f"D.{mode}.{k}")
+
+
+@pytest.mark.parametrize("rescale", [True, False])
+def test_mnist_ali_steps_vs_oracle(rescale):
+    """3 iterations at bs=64 (BASELINE config 1 shape), reference init (losses at ln 2) and O(1) init."""
+    import ali_hip
+    from image_scms.training_utils import ali_step
+    (Eo, Go, Do), (E, G, D), _, _, _ = paired_models("mnist", rescale=rescale)
+    x, a = orc.synth_morphomnist(192, seed=1)
+    stats = {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"}
+    oe, od = orc.build_optimizers(Eo, Go, Do, "mnist")
+    pe = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=1e-4, betas=(0.5, 0.999))
+    pd = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    for m in (Eo, Go, Do, E, G, D):
+        m.train()
+    torch.manual_seed(123)
+    for i in range(3):
+        images, c = orc.mnist_scale_batch(x[i * 64:(i + 1) * 64], {k: v[i * 64:(i + 1) * 64] for k, v in a.items()},
+                                          stats)
+        z = torch.randn(64, 512, 1, 1)
+        tape = orc.MaskTape()
+        ro = orc.ali_step(Eo, Go, Do, oe, od, images, c, z, tape=tape)
+        with ali_hip.injected_masks(tape.masks):
+            rp = ali_step(E, G, D, pe, pd, images.cuda(), to_dev(c), z.cuda())
+        for k in ("loss_eg", "loss_d_real", "loss_d_fake", "dg", "de"):
+            assert abs(rp[k].item() - ro[k]) <= 1e-5 * max(1.0, abs(ro[k])), (i, k, rp[k].item(), ro[k])
+    for nm, mo, mp in (("E", Eo, E), ("G", Go, G), ("D", Do, D)):
+        so = mo.state_dict()
+        for k, v in mp.state_dict().items():
+            # Adam's first steps move every weight by ~lr regardless of gradient scale: compare updates tightly
+            close(v.float(), so[k].float(), 2e-4, f"{nm}.{k} after 3 steps")
+    # reconstructions G(E(x)) within 1e-3 (north_star)
+    with torch.no_grad():
+        for m in (Eo, Go, E, G):
+            m.eval()
+        close(G(E(images.cuda(), to_dev(c)), to_dev(c)), Go(Eo(images, c), c), 1e-3, "G(E(x))")
+
+
+def test_callers_finetune_and_generator_score(golden_dir):
+    """finetune_mnist_bigan.py:64-85 and mnist_generator_score.py:69-74 access patterns against the golden trace."""
+    import os
+    import image_scms.mnist as pm
+    g = np.load(os.path.join(golden_dir, "callers_mnist.npz"), allow_pickle=False)
+    torch.manual_seed(31)
+    np.random.seed(31)
+    E, G = pm.Encoder(), pm.Generator()
+    E.apply(pm.init_weights), G.apply(pm.init_weights)
+    orc.rescale_for_test_(E, 0.01, bias_seed=7), orc.rescale_for_test_(G, 0.01, bias_seed=8)
+    E, G = E.cuda(), G.cuda()
+    xs, a = orc.synth_morphomnist(8, seed=4)
+    stats = {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"}
+    x, c = orc.mnist_scale_batch(xs, a, stats)
+    x, c = x.cuda(), to_dev(c)
+    E.train(), G.eval()
+    opt = torch.optim.Adam(E.parameters(), lr=1e-4)
+    rec, lat = [], []
+    for _ in range(2):
+        opt.zero_grad()
+        codes = E(x, c)
+        rl = torch.square(x - G(codes, c)).mean()
+        ll = torch.square(codes).mean()
+        (rl + ll).backward()
+        opt.step()
+        rec.append(rl.item()), lat.append(ll.item())
+    np.testing.assert_allclose(rec, g["rec"], rtol=1e-4)
+    np.testing.assert_allclose(lat, g["lat"], rtol=1e-4)
+    with torch.no_grad():
+        gen = G(torch.randn(8, 512, 1, 1, generator=torch.Generator().manual_seed(6)).cuda(), c)
+    np.testing.assert_allclose(gen.reshape(8, -1)[:, 300:364].cpu().numpy(), g["gen_head"], rtol=1e-3, atol=1e-4)
+
+
+def test_hip_library_is_loaded_and_mandatory():
+    import ali_hip
+    lib = ali_hip.load()
+    assert lib.ali_version() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libali_hip.so" in f.read()
