@@ -1,0 +1,203 @@
+"""ALI training throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one full ALI iteration (E+G update, two D updates, diagnostics: everything in the reference's
+image_scms/mnist.py:204-248) on one synthetic MorphoMNIST-shaped batch of 512 images per GPU, inputs already
+resident in HBM.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, timed live with HIP events on
+the launch stream in an extra instrumented iteration) and `cpu_baseline` (the CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "imagecfgen-pytorch_amd"))
+
+BS_PER_GPU = 512
+# algorithmic work per image of the minimal schedule at B=512 (fp32 storage)
+ALG_BYTES_PER_IMG = 8108239.0
+ALG_FLOP_PER_IMG = 1.0026e9
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(bs, device, seed):
+    """MorphoMNIST-shaped synthetic batch: images in [-1,1], one-hot digit, 3 scaled attributes."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, 256, (bs, 28, 28), generator=g).float() * (torch.rand(bs, 28, 28, generator=g) > 0.8)
+    images = (2 * x / 255 - 1).reshape(bs, 1, 28, 28)
+    c = {"digit": torch.nn.functional.one_hot(torch.randint(0, 10, (bs,), generator=g), 10).float(),
+         "thickness": torch.rand(bs, 1, generator=g) * 2 - 1, "intensity": torch.rand(bs, 1, generator=g) * 2 - 1,
+         "slant": torch.rand(bs, 1, generator=g) * 2 - 1}
+    z = torch.randn(bs, 512, 1, 1, generator=g)
+    return images.to(device), {k: v.to(device) for k, v in c.items()}, z.to(device)
+
+
+def cpu_baseline(bs, budget_s=25.0):
+    """The CPU oracle (torch-CPU restatement of the reference iteration, bit-identical to the reference in the
+    build container) timed on this host: 1 warm-up + as many iterations as fit in the budget (>= 2)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ali_oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    E, G, D = orc.build_models("mnist")
+    oe, od = orc.build_optimizers(E, G, D)
+    for m in (E, G, D):
+        m.train()
+    images, c, z = synth_batch(bs, "cpu", 1)
+    orc.ali_step(E, G, D, oe, od, images, c, z)
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 8):
+        orc.ali_step(E, G, D, oe, od, images, c, z)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} ALI iterations at bs={bs} after 1 warm-up, torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BS_PER_GPU)
+    ap.add_argument("--mode", default="stepper", choices=["stepper", "autograd"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    import ali_hip
+    import image_scms.mnist as pm
+    from ali_hip import ops
+    from ali_hip.step import AliStepper
+    from image_scms.training_utils import ali_step
+    ali_hip.load()
+
+    torch.manual_seed(1)                       # identical replicas; per-rank data / z / dropout streams
+    E, G, D = pm.Encoder(), pm.Generator(), pm.Discriminator()
+    for m in (E, G, D):
+        m.apply(pm.init_weights)
+        m.to(dev).train()
+    ali_hip.manual_seed(1234 + rank)
+    bs = args.batch
+    batches = [synth_batch(bs, dev, 100 + rank * 17 + i) for i in range(4)]
+
+    if args.mode == "stepper":
+        stepper = AliStepper(E, G, D, process_group=pg, capture=not args.no_graph)
+
+        def one(i):
+            images, c, z = batches[i % len(batches)]
+            return stepper.step(images, c, z)
+    else:
+        assert world == 1, "autograd mode is single-GPU (reference schedule through torch.autograd)"
+        oe = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=1e-4, betas=(0.5, 0.999))
+        od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+
+        def one(i):
+            images, c, z = batches[i % len(batches)]
+            return ali_step(E, G, D, oe, od, images, c, z)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        r = one(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        r = one(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    losses = {k: float(v) for k, v in r.items()}
+
+    # ---- roofline leg: one instrumented eager iteration on every rank (collectives stay matched),
+    # HIP events around every GEMM launch on rank 0
+    prof = ops.KernelProfile()
+    if rank == 0:
+        ops.set_profile(prof)
+    if args.mode == "stepper":
+        keep, stepper.capture = stepper.capture, False
+        one(0)
+        stepper.capture = keep
+    else:
+        one(0)
+    ops.set_profile(None)
+    fence()
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = bs * world * args.steps / dt
+        per_gpu = value / world
+        fam = prof.summary() if prof.records else {}
+        roof = None
+        if fam:
+            name = max(fam, key=lambda k: fam[k]["ms"])
+            f = fam[name]
+            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": {"gconv": "ali::gconv_kernel", "wgrad": "ali::wgrad_kernel"}[name],
+                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": f["launches"], "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2),
+                    "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()}}
+        out = {
+            "metric": "ALI training images/sec (E+G+D step), MorphoMNIST bs=512/GPU", "value": round(value, 1),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "image_scms/mnist.py ALI iteration (EG step + 2 D steps + diagnostics), "
+                                   f"MorphoMNIST 28x28x1 synthetic, bs={bs}/GPU, fp32 MFMA, mode={args.mode}"
+                                   f"{'' if args.no_graph or world > 1 or args.mode != 'stepper' else '+hipgraph'}",
+                       "global_batch": bs * world, "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "step_roofline": {"hbm_frac": round(per_gpu * ALG_BYTES_PER_IMG / (PEAK_HBM_GBS * 1e9), 4),
+                              "mfma_f32_frac": round(per_gpu * ALG_FLOP_PER_IMG / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                              "alg_bytes_per_img": ALG_BYTES_PER_IMG, "alg_flop_per_img": ALG_FLOP_PER_IMG},
+            "losses_last_step": losses,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(bs)
+        else:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -40,7 +40,7 @@ SIGNATURES = {
     "ali_act_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "ali_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ali_rowmask_mul": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
-    "ali_dropout_mask": (c_int32, [c_uint64, c_uint64, c_float, c_void_p, c_int64, c_void_p]),
+    "ali_dropout_mask": (c_int32, [c_uint64, c_uint64, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "ali_bn_stats": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
@@ -50,7 +50,7 @@ SIGNATURES = {
                              c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ali_bce_logits": (c_int32, [c_void_p, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "ali_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
-                           c_int32, c_void_p]),
+                           c_int32, c_void_p, c_float, c_void_p]),
     "ali_assemble_planes": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_int32, c_void_p,
                                       c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ali_last_error": (c_char_p, []),

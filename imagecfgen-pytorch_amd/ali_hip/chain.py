@@ -35,21 +35,34 @@ class Stage:
 
 
 class PackCache:
-    """Kernel-layout copies of one parameter, refreshed when the parameter's version changes
-    (the reference layouts stay the master copies: Conv [Cout,Cin,kh,kw], ConvT [Cin,Cout,kh,kw], Linear [out,in])."""
+    """Kernel-layout copies of one parameter (the reference layouts stay the master copies: Conv
+    [Cout,Cin,kh,kw], ConvT [Cin,Cout,kh,kw], Linear [out,in]).
+
+    Dynamic mode (autograd modules): a copy is rebuilt when the parameter's version / storage changes.
+    Static mode (AliStepper, graph capture): buffers keep their addresses and are refreshed explicitly
+    by ``refresh()`` right after the optimiser kernel that changed the parameters."""
 
     def __init__(self):
         self.store = {}
+        self.static = False
 
     def get(self, key, param: torch.Tensor, builder):
-        tag = (param.data_ptr(), param._version, tuple(param.shape))
         hit = self.store.get(key)
+        if self.static and hit is not None:
+            return hit[1]
+        tag = (param.data_ptr(), param._version, tuple(param.shape))
         if hit is not None and hit[0] == tag:
             return hit[1]
         with torch.no_grad():
-            val = builder()
-        self.store[key] = (tag, val)
+            val = builder(hit[1] if (hit is not None and self.static) else None)
+        self.store[key] = (tag, val, builder)
         return val
+
+    def refresh(self):
+        with torch.no_grad():
+            for key, (tag, val, builder) in list(self.store.items()):
+                out = builder(val)
+                assert out.data_ptr() == val.data_ptr()
 
 
 class ChainPlan:
@@ -109,35 +122,38 @@ class ChainPlan:
         w = st.mod.weight
         dev = w.device
 
-        def build():
+        def build(dst=None):
+            def buf(*shape, zero=False):
+                if dst is not None:
+                    return dst.reshape(shape)
+                return (torch.zeros if zero else torch.empty)(*shape, device=dev)
             if st.kind == "conv":
                 K, C, R, S = w.shape
                 T = R * S
                 if which == "fwd":      # [K][T][Cpad]
-                    dst = torch.empty(K, T, cin_stride, device=dev)
-                    return ops.pack_weights(w.detach(), dst, K, T, C, cin_stride, C * T, 1, T)
-                dst = torch.zeros(cin_stride, T, K, device=dev)   # [Cpad][T][K]; rows >= C stay zero
-                ops.pack_weights(w.detach(), dst, C, T, K, K, T, 1, C * T)
-                return dst
+                    return ops.pack_weights(w.detach(), buf(K, T, cin_stride), K, T, C, cin_stride, C * T, 1, T)
+                out = buf(cin_stride, T, K, zero=True)             # [Cpad][T][K]; rows >= C stay zero
+                ops.pack_weights(w.detach(), out, C, T, K, K, T, 1, C * T)
+                return out
             if st.kind == "convT":
                 Ci, Co, R, S = w.shape
                 T = R * S
                 if which == "fwd":      # convT forward == data-gradient GEMM: [Co][T][Ci_pad]
-                    dst = torch.empty(Co, T, cin_stride, device=dev)
-                    return ops.pack_weights(w.detach(), dst, Co, T, Ci, cin_stride, T, 1, Co * T)
-                dst = torch.empty(Ci, T, Co, device=dev)           # convT dgrad == conv forward GEMM: [Ci][T][Co]
-                return ops.pack_weights(w.detach(), dst, Ci, T, Co, Co, Co * T, 1, T)
+                    return ops.pack_weights(w.detach(), buf(Co, T, cin_stride), Co, T, Ci, cin_stride, T, 1, Co * T)
+                # convT dgrad == conv forward GEMM: [Ci_pad][T][Co]; rows >= Ci stay zero
+                out = buf(cin_stride, T, Co, zero=True)
+                ops.pack_weights(w.detach(), out, Ci, T, Co, Co, Co * T, 1, T)
+                return out
             # linear (+Unflatten(C,h,w)): 1x1 conv whose output channel n' = t*C + co is NHWC [B,h,w,C]
             O, I = w.shape
             Cc, hh, ww = st.unflat if st.unflat else (O, 1, 1)
             T = hh * ww
-            fwd = torch.empty(T, Cc, cin_stride, device=dev)
-            ops.pack_weights(w.detach(), fwd, T, Cc, I, cin_stride, I, T * I, 1)
             if which == "fwd":
-                return fwd.reshape(O, 1, cin_stride)
-            dst = torch.zeros(cin_stride, 1, O, device=dev)        # [I_pad][1][O] = transpose of the fwd pack
-            ops.pack_weights(fwd, dst, I, 1, O, O, 1, 0, cin_stride)
-            return dst
+                return ops.pack_weights(w.detach(), buf(O, 1, cin_stride), T, Cc, I, cin_stride, I, T * I, 1)
+            fwd = self.packed(st, "fwd", cin_stride)
+            out = buf(cin_stride, 1, O, zero=True)                 # [I_pad][1][O] = transpose of the fwd pack
+            ops.pack_weights(fwd, out, I, 1, O, O, 1, 0, cin_stride)
+            return out
 
         return self.cache.get((st.index, which, cin_stride), w, build)
 
@@ -148,8 +164,13 @@ class ChainPlan:
         if st.kind != "linear" or not st.unflat:
             return b.detach()
         Cc, hh, ww = st.unflat
-        return self.cache.get((st.index, "bias"), b,
-                              lambda: b.detach().reshape(Cc, hh * ww).t().contiguous().reshape(-1))
+        def build(dst=None):
+            val = b.detach().reshape(Cc, hh * ww).t().contiguous().reshape(-1)
+            if dst is not None:
+                dst.copy_(val)
+                return dst
+            return val
+        return self.cache.get((st.index, "bias"), b, build)
 
 
 # ---------------------------------------------------------------------- shapes
@@ -243,9 +264,12 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
     return cur, saved
 
 
-def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True):
-    """Returns (gx or None, {param tensor id -> grad})."""
+def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True,
+                   grad_dst=None):
+    """Returns (gx or None, {param tensor id -> grad}).  ``grad_dst`` optionally maps id(param) to a
+    preallocated destination (a view of a flat gradient buffer) that the kernels write directly."""
     grads = {}
+    grad_dst = grad_dst or {}
     n = len(plan.stages)
     last = plan.stages[-1]
     gy = gy.contiguous()
@@ -266,11 +290,13 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             if m.bias is not None:
                 if st.kind == "linear" and st.unflat:
                     Cc, hh, ww = st.unflat
-                    db = ops.colsum(B, hh * ww * Cc, hh * ww * Cc, g_pre)
-                    grads[id(m.bias)] = db.reshape(hh * ww, Cc).t().reshape(-1)
+                    db = ops.colsum(B, hh * ww * Cc, hh * ww * Cc, g_pre).reshape(hh * ww, Cc).t().reshape(-1)
+                    if id(m.bias) in grad_dst:
+                        db = grad_dst[id(m.bias)].copy_(db)
+                    grads[id(m.bias)] = db
                 else:
-                    grads[id(m.bias)] = ops.colsum(rows_out, K, K, g_pre)
-            dw = torch.empty_like(m.weight)
+                    grads[id(m.bias)] = ops.colsum(rows_out, K, K, g_pre, out=grad_dst.get(id(m.bias)))
+            dw = grad_dst[id(m.weight)] if id(m.weight) in grad_dst else torch.empty_like(m.weight)
             if st.kind == "conv":
                 T = m.kernel_size[0] * m.kernel_size[1]
                 ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1)
@@ -312,6 +338,8 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             dgam, dbet, gprev = ops.bn_bwd(sv.x_in, gt, mask_in, mask_pre, sv.bn_stats, bn.weight.detach(), B, H * W,
                                            Cp, use_batch, slope, want_gx=want)
             if need_params:
+                if id(bn.weight) in grad_dst:
+                    dgam, dbet = grad_dst[id(bn.weight)].copy_(dgam), grad_dst[id(bn.bias)].copy_(dbet)
                 grads[id(bn.weight)] = dgam
                 grads[id(bn.bias)] = dbet
             if pact == ACT_TANH and gprev is not None:

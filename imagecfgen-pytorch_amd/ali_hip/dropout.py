@@ -12,7 +12,7 @@ import torch
 
 from . import ops
 
-_state = {"seed": 0x5EED, "offset": 0, "inject": None, "pos": 0}
+_state = {"seed": 0x5EED, "offset": 0, "inject": None, "pos": 0, "dev_counter": None}
 
 
 def manual_seed(seed: int):
@@ -29,6 +29,12 @@ def injected_masks(masks):
         _state["inject"], _state["pos"] = prev
 
 
+def begin_iteration(dev_counter):
+    """Stepper hook: masks of this iteration are keyed by the device-side iteration counter (graph replays
+    read its current value) and by positions that restart at 0 every iteration."""
+    _state["dev_counter"], _state["offset"] = dev_counter, 0
+
+
 def masks_consumed() -> int:
     return _state["pos"]
 
@@ -43,6 +49,6 @@ def next_mask(B: int, C: int, p: float, device) -> torch.Tensor:
         if tuple(m.shape) != (B, C):
             raise RuntimeError(f"injected mask shape {tuple(m.shape)} != {(B, C)}")
         return m.to(device=device, dtype=torch.float32).contiguous()
-    m = ops.dropout_mask(_state["seed"], _state["offset"], p, B, C, device)
+    m = ops.dropout_mask(_state["seed"], _state["offset"], p, B, C, device, _state["dev_counter"])
     _state["offset"] += B * C
     return m

@@ -61,28 +61,74 @@ def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=AC
     return ep
 
 
+class KernelProfile:
+    """Live per-launch timing of the GEMM kernels with HIP events on the launch stream
+    (bench.py's roofline leg).  Each record: (family, algorithmic flops, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, flops, e0, e1 in self.records:
+            f = fam.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            f["launches"] += 1
+            f["flops"] += flops
+            f["ms"] += e0.elapsed_time(e1)
+        return fam
+
+
+_PROFILE = None
+
+
+def set_profile(p):
+    global _PROFILE
+    _PROFILE = p
+
+
+class _Timed:
+    def __init__(self, name, g: AliConvGeom):
+        self.name = name
+        self.flops = 2.0 * g.B * g.P * g.Q * g.K * g.C * g.R * g.S
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.e1.record()
+            _PROFILE.records.append((self.name, self.flops, self.e0, self.e1))
+
+
 def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
     lib = _lib.load()
     ws = workspace(x.device)
-    _lib.check(lib.ali_conv_fwd(byref(g), _chk(x, "x"), _chk(w_packed, "w"), _chk(y, "y"), byref(ep),
-                                c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
+    with _Timed("gconv", g):
+        _lib.check(lib.ali_conv_fwd(byref(g), _chk(x, "x"), _chk(w_packed, "w"), _chk(y, "y"), byref(ep),
+                                    c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
     return y
 
 
 def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
     lib = _lib.load()
     ws = workspace(dy.device)
-    _lib.check(lib.ali_conv_bwd_data(byref(g), _chk(dy, "dy"), _chk(w_packed, "w"), _chk(dx, "dx"), byref(ep),
-                                     c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
+    with _Timed("gconv", g):
+        _lib.check(lib.ali_conv_bwd_data(byref(g), _chk(dy, "dy"), _chk(w_packed, "w"), _chk(dx, "dx"), byref(ep),
+                                         c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
     return dx
 
 
 def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap):
     lib = _lib.load()
     ws = workspace(x.device)
-    _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
-                                       s_dc, s_gc, s_tap, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-               "ali_conv_bwd_weight")
+    with _Timed("wgrad", g):
+        _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
+                                           s_dc, s_gc, s_tap, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                   "ali_conv_bwd_weight")
     return dst
 
 
@@ -118,10 +164,14 @@ def rowmask_mul(x, mask, B, rows_per_img, C, out=None):
     return out
 
 
-def dropout_mask(seed, offset, p, B, C, device):
+def dropout_mask(seed, offset, p, B, C, device, dev_counter=None):
     lib = _lib.load()
     out = torch.empty(B, C, dtype=torch.float32, device=device)
-    _lib.check(lib.ali_dropout_mask(seed, offset, p, _chk(out), out.numel(), _stream()), "ali_dropout_mask")
+    ctr = None
+    if dev_counter is not None:
+        assert dev_counter.is_cuda and dev_counter.dtype == torch.int64
+        ctr = c_void_p(dev_counter.data_ptr())
+    _lib.check(lib.ali_dropout_mask(seed, offset, ctr, p, _chk(out), out.numel(), _stream()), "ali_dropout_mask")
     return out
 
 
@@ -169,10 +219,14 @@ def bce_logits(logit, target, gscale=1.0, want_grad=True):
     return out2, gl
 
 
-def adam(p, g, m, v, lr, beta1, beta2, eps, step):
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0):
     lib = _lib.load()
+    ds = None
+    if dev_step is not None:
+        assert dev_step.is_cuda and dev_step.dtype == torch.int32
+        ds = c_void_p(dev_step.data_ptr())
     _lib.check(lib.ali_adam(_chk(p, "p"), _chk(g, "g"), _chk(m, "m"), _chk(v, "v"), p.numel(), lr, beta1, beta2, eps,
-                            step, _stream()), "ali_adam")
+                            step, ds, grad_scale, _stream()), "ali_adam")
 
 
 def assemble_planes(X, idx, tables, cont, B, H, W, Cpad):

@@ -1,0 +1,315 @@
+"""Hand-scheduled ALI/BiGAN iteration on the HIP kernels (no autograd engine).
+
+Reproduces the reference loop body (image_scms/mnist.py:224-248 and its copies
+audio_mnist.py:384-420, whalecalls.py:462-498, esrf_acoustic.py:341-377) with the
+work the reference computes and then throws away removed:
+
+  EG step   E(x), D(x,E(x)), G(z), D(G(z),z); backward only along the paths that reach
+            E and G: dxz -> dz -> E for the real branch, dxz -> dx -> G for the fake branch;
+            no Discriminator weight gradients (the reference zeroes them before use).
+  D step a  E'(x) forward only, D full backward, Adam(D).
+  D step b  G'(z) forward only, D full backward, Adam(D).
+  scores    D''(G'(z), z), D''(x, E'(x)) forward only, re-using G'(z) and E'(x) (the
+            reference recomputes identical values) -- train mode, so Dropout2d is active and
+            the BatchNorm running statistics get their 6 updates per iteration.
+
+Parameters live in two flat fp32 buffers (E+G, D) with flat gradient / Adam-moment
+twins, so an optimiser step is one kernel launch and a data-parallel gradient exchange is
+one RCCL all-reduce per group.  Kernel-layout weight copies have fixed addresses and are
+re-packed right after the Adam launch that changed them, which makes the whole iteration
+capturable in a HIP graph (``capture=True``).
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import dropout as _dropout
+from . import ops
+from .chain import chain_backward, chain_forward, get_plan
+
+
+class FlatGroup:
+    """Parameters re-pointed into one flat buffer + flat grad / exp_avg / exp_avg_sq buffers."""
+
+    def __init__(self, params, lr, betas, eps):
+        self.params = list(params)
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.flat = torch.empty(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.grad_views = {}
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                gv = self.grad[off:off + k].view(p.shape)
+                p.grad = gv
+                self.grad_views[id(p)] = gv
+                off += k
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.steps = 0
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)
+
+    def adam(self, grad_scale=1.0):
+        self.steps += 1
+        self.step_t += 1
+        ops.adam(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.steps,
+                 dev_step=self.step_t, grad_scale=grad_scale)
+
+    # torch.optim-like surface for callers that keep the returned optimisers
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def step(self):
+        self.adam()
+
+    def state_dict(self):
+        return {"step": self.steps, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas,
+                "eps": self.eps}
+
+
+class MnistFamily:
+    """Input assembly of the MorphoMNIST models (mnist.py:46-55, 76-85, 142-151)."""
+    name = "mnist"
+    hw = (28, 28)
+
+    def __init__(self, E, G, D):
+        self.e_tables = [E.digit_embedding[0].weight]
+        self.d_tables = [D.digit_embedding[0].weight]
+        self.g_tables = [G.digit_embedding.weight]
+
+    @staticmethod
+    def conditioning(c):
+        keys = sorted(k for k in c if k != "digit")
+        B = c["digit"].shape[0]
+        idx = c["digit"].argmax(1).to(torch.int32).reshape(B, 1).contiguous()
+        cont = torch.cat([c[k].reshape(B, 1).float() for k in keys], dim=1).contiguous() if keys else None
+        onehots = [c["digit"].float()]
+        return idx, cont, onehots
+
+
+class AliStepper:
+    def __init__(self, E, G, D, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, family=None, process_group=None,
+                 capture=False):
+        self.E, self.G, self.D = E, G, D
+        self.family = family or MnistFamily(E, G, D)
+        self.pE, self.pG = get_plan(E.layers), get_plan(G.layers)
+        self.pDx, self.pDz, self.pDxz = get_plan(D.dx), get_plan(D.dz), get_plan(D.dxz)
+        self.opt_eg = FlatGroup(list(E.parameters()) + list(G.parameters()), lr, betas, eps)
+        self.opt_d = FlatGroup(list(D.parameters()), lr, betas, eps)
+        for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
+            pl.cache.store.clear()
+            pl.cache.static = True
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.capture = capture
+        self._graph = None
+        self._static = None
+        self.bn_buffers = [b for n_, b in D.named_buffers() if "running" in n_]
+        self.iter_t = torch.zeros(1, dtype=torch.int64, device=self.opt_d.flat.device)
+
+    # ------------------------------------------------------------------ pieces
+    def _planes(self, X, idx, cont, tables):
+        B = X.shape[0]
+        H, W = self.family.hw
+        n_log = 1 + len(tables) + (0 if cont is None else cont.shape[1])
+        out = ops.assemble_planes(X.reshape(B, H, W), idx, [t.detach() for t in tables], cont, B, H, W,
+                                  (n_log + 3) // 4 * 4)
+        return out, n_log
+
+    def _plane_grads(self, g0, x0, idx, tables, dst):
+        """Embedding-table gradients from the gradient of the assembled planes (tiny tensors)."""
+        from .planes import _src_index
+        B, H, W, _ = g0.shape
+        src = _src_index(H, W, g0.device)
+        for j, t in enumerate(tables):
+            plane = x0[..., 1 + j].reshape(B, H * W)
+            gp = g0[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)
+            per_sample = torch.zeros(B, 256, device=g0.device).index_add_(1, src, gp)
+            dst[id(t)].zero_().index_add_(0, idx[:, j].long(), per_sample)
+
+    def _g_input(self, z, onehots, cont):
+        B = z.shape[0]
+        feats = [z.reshape(B, -1).float()] + [oh.matmul(t.detach()) for oh, t in zip(onehots, self.family.g_tables)]
+        if cont is not None:
+            feats.append(cont)
+        n_log = sum(f.shape[1] for f in feats)
+        pad = (-n_log) % 4
+        if pad:
+            feats.append(torch.zeros(B, pad, device=z.device))
+        return torch.cat(feats, dim=1).reshape(B, 1, 1, n_log + pad), n_log
+
+    def _d_forward(self, x0, n_log, zin, save):
+        B = x0.shape[0]
+        dx, s_dx = chain_forward(self.pDx, x0, True, n_log, save)
+        dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save)
+        joint = torch.cat([dx.reshape(B, -1), dz.reshape(B, -1)], dim=1).reshape(B, 1, 1, -1)
+        logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save)
+        return logit.reshape(B, 1), (s_dx, s_dz, s_dxz, dx.shape[-1], n_log)
+
+    def _d_backward(self, saved, glogit, need_params, need_x, need_z):
+        s_dx, s_dz, s_dxz, n_dx, n_log = saved
+        B = glogit.shape[0]
+        dst = self.opt_d.grad_views if need_params else None
+        gjoint, _ = chain_backward(self.pDxz, s_dxz, glogit.reshape(B, 1, 1, 1), s_dxz[0].in_shape[3], True,
+                                   need_params, dst)
+        gjoint = gjoint.reshape(B, -1)
+        gx0 = gz = None
+        if need_params or need_x:
+            gx0, _ = chain_backward(self.pDx, s_dx, gjoint[:, :n_dx].contiguous().reshape(B, 1, 1, n_dx), n_log,
+                                    need_x, need_params, dst)
+        if need_params or need_z:
+            nz = gjoint.shape[1] - n_dx
+            gz, _ = chain_backward(self.pDz, s_dz, gjoint[:, n_dx:].contiguous().reshape(B, 1, 1, nz), nz, need_z,
+                                   need_params, dst)
+        return gx0, gz
+
+    def _reduce_and_step(self, group: FlatGroup):
+        """DP: one RCCL all-reduce(sum) of the flat gradient; the 1/world average is folded into Adam."""
+        if self.world > 1:
+            torch.distributed.all_reduce(group.grad, group=self.pg)
+        group.adam(1.0 / self.world)
+
+    # ------------------------------------------------------------------ the iteration
+    def _iteration(self, images, c, z, do_eg=True):
+        fam = self.family
+        B = images.shape[0]
+        self.iter_t += 1
+        _dropout.begin_iteration(self.iter_t)
+        idx, cont, onehots = fam.conditioning(c)
+        out = {}
+        zin = z.reshape(B, -1).float().contiguous()
+        if do_eg:
+            x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
+            ex, sE = chain_forward(self.pE, x0e, True, n_log, True)
+            x0d, _ = self._planes(images, idx, cont, fam.d_tables)
+            d_valid, sD1 = self._d_forward(x0d, n_log, ex, True)
+            gin, g_log = self._g_input(zin, onehots, cont)
+            gz, sG = chain_forward(self.pG, gin, True, g_log, True)
+            x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
+            d_fake, sD2 = self._d_forward(x0f, n_log, zin, True)
+            l1, gl1 = ops.bce_logits(d_valid, 0.0, 0.5)
+            l2, gl2 = ops.bce_logits(d_fake, 1.0, 0.5)
+            out["loss_eg"] = (l1[0] + l2[0]) / 2
+            # real branch: only the z-side path reaches E
+            _, g_ex = self._d_backward(sD1, gl1, False, False, True)
+            dst = self.opt_eg.grad_views
+            g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, True, True, dst)
+            self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
+            # fake branch: only the image path reaches G
+            g_x0f, _ = self._d_backward(sD2, gl2, False, True, False)
+            g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
+            g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst)
+            g_gin = g_gin.reshape(B, -1)
+            off = zin.shape[1]
+            for oh, t in zip(onehots, fam.g_tables):
+                dst[id(t)].copy_(oh.t().matmul(g_gin[:, off:off + 256]))
+                off += 256
+            del sE, sG, sD1, sD2
+            self._reduce_and_step(self.opt_eg)
+            self.pE.cache.refresh()
+            self.pG.cache.refresh()
+        # ---- D step a: real pair with the updated encoder
+        x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
+        ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
+        x0d, _ = self._planes(images, idx, cont, fam.d_tables)
+        d_valid, sD = self._d_forward(x0d, n_log, ex, True)
+        l, gl = ops.bce_logits(d_valid, 1.0, 1.0)
+        out["loss_d_real"] = l[0]
+        g_x0, _ = self._d_backward(sD, gl, True, True, False)
+        self._plane_grads(g_x0, x0d, idx, fam.d_tables, self.opt_d.grad_views)
+        del sD
+        self._reduce_and_step(self.opt_d)
+        self._refresh_d()
+        # ---- D step b: fake pair with the updated generator
+        gin, g_log = self._g_input(zin, onehots, cont)
+        gz, _ = chain_forward(self.pG, gin, True, g_log, False)
+        x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
+        d_fake, sD = self._d_forward(x0f, n_log, zin, True)
+        l, gl = ops.bce_logits(d_fake, 0.0, 1.0)
+        out["loss_d_fake"] = l[0]
+        g_x0, _ = self._d_backward(sD, gl, True, True, False)
+        self._plane_grads(g_x0, x0f, idx, fam.d_tables, self.opt_d.grad_views)
+        del sD
+        self._reduce_and_step(self.opt_d)
+        self._refresh_d()
+        # ---- diagnostics (forward only, train mode; re-uses G'(z) and E'(x))
+        x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
+        dg, _ = self._d_forward(x0f, n_log, zin, False)
+        x0d, _ = self._planes(images, idx, cont, fam.d_tables)
+        de, _ = self._d_forward(x0d, n_log, ex, False)
+        out["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
+        out["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
+        if self.world > 1 and self.bn_buffers:
+            # replicas use local batch statistics; keep the running buffers (state_dict) identical
+            flat = torch.cat([b.reshape(-1) for b in self.bn_buffers])
+            torch.distributed.all_reduce(flat, group=self.pg)
+            flat.mul_(1.0 / self.world)
+            off = 0
+            for b in self.bn_buffers:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+        return out
+
+    def _state_tensors(self):
+        ts = [self.iter_t]
+        for g in (self.opt_eg, self.opt_d):
+            ts += [g.flat, g.m, g.v, g.step_t]
+        ts += [b for _, b in self.D.named_buffers()]
+        return ts
+
+    def _snapshot(self):
+        return [t.clone() for t in self._state_tensors()], (self.opt_eg.steps, self.opt_d.steps)
+
+    def _restore(self, snap):
+        vals, (se, sd) = snap
+        for t, v in zip(self._state_tensors(), vals):
+            t.copy_(v)
+        self.opt_eg.steps, self.opt_d.steps = se, sd
+        for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
+            pl.cache.refresh()
+
+    def _refresh_d(self):
+        self.pDx.cache.refresh()
+        self.pDz.cache.refresh()
+        self.pDxz.cache.refresh()
+
+    # ------------------------------------------------------------------ public
+    @torch.no_grad()
+    def step(self, images, c: Dict[str, torch.Tensor], z, do_eg=True, masks=None):
+        """One iteration.  ``masks``: optional list of host-recorded Dropout2d masks (parity mode)."""
+        if masks is not None:
+            with _dropout.injected_masks(masks):
+                return self._iteration(images, c, z, do_eg)
+        if not self.capture or self.world > 1:
+            return self._iteration(images, c, z, do_eg)
+        return self._replay(images, c, z, do_eg)
+
+    def _replay(self, images, c, z, do_eg):
+        key = (tuple(images.shape), do_eg)
+        if self._graph is None or self._graph[0] != key:
+            st = {"images": images.clone(), "z": z.clone(), "c": {k: v.clone() for k, v in c.items()}}
+            snap = self._snapshot()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):          # warm-up outside capture: packs, workspace, plans
+                self._iteration(st["images"], st["c"], st["z"], do_eg)
+            torch.cuda.current_stream().wait_stream(s)
+            self._restore(snap)                 # the warm-up must not count as a training iteration
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = self._iteration(st["images"], st["c"], st["z"], do_eg)
+            self._graph = (key, graph, st, res)
+        _, graph, st, res = self._graph
+        st["images"].copy_(images)
+        st["z"].copy_(z)
+        for k, v in c.items():
+            st["c"][k].copy_(v)
+        graph.replay()
+        return res

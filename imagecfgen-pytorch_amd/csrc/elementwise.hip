@@ -89,12 +89,14 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__global__ void dropout_mask_kernel(uint64_t seed, uint64_t offset, float p, float* __restrict__ out, long long n) {
+__global__ void dropout_mask_kernel(uint64_t seed, uint64_t offset, const long long* __restrict__ dev_counter, float p,
+                                    float* __restrict__ out, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
   const float keep = 1.f - p, inv = 1.f / (1.f - p);
+  const uint64_t key = mix64(mix64(seed) ^ (dev_counter ? (uint64_t)dev_counter[0] * 0xD1B54A32D192ED03ull : 0ull));
   for (; i < n; i += step) {
-    const uint64_t r = mix64(mix64(seed) ^ (offset + (uint64_t)i));
+    const uint64_t r = mix64(key ^ (offset + (uint64_t)i));
     const float u = (float)(r >> 40) * (1.f / 16777216.f);
     out[i] = u < keep ? inv : 0.f;
   }
@@ -294,12 +296,15 @@ __global__ void bce_logits_kernel(const float* __restrict__ logit, int B, float 
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                            float bc1, float bc2_sqrt) {
+                            int step_host, const int* __restrict__ dev_step, float grad_scale) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
+  const int t = dev_step ? dev_step[0] : step_host;
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)t));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
   const float step_size = lr / bc1;
   for (; i < n; i += step) {
-    const float gi = g[i];
+    const float gi = g[i] * grad_scale;
     const float w = 1.f - b1;                                    // exp_avg.lerp_(grad, 1-beta1): torch's two-branch lerp
     const float mi = w < 0.5f ? m[i] + w * (gi - m[i]) : gi - (gi - m[i]) * (1.f - w);
     const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
@@ -385,9 +390,11 @@ extern "C" int ali_rowmask_mul(const float* x, const float* mask, float* out, in
   return check_launch("rowmask_mul_kernel");
 }
 
-extern "C" int ali_dropout_mask(uint64_t seed, uint64_t offset, float p, float* out, int64_t n, ali_stream_t stream) {
+extern "C" int ali_dropout_mask(uint64_t seed, uint64_t offset, const int64_t* dev_counter, float p, float* out,
+                                int64_t n, ali_stream_t stream) {
   if (!out || n <= 0 || !(p >= 0.f && p < 1.f)) { set_error("ali_dropout_mask: bad argument"); return ALI_ERR_BAD_ARG; }
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), seed, offset, p, out, (long long)n);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), seed, offset,
+                     reinterpret_cast<const long long*>(dev_counter), p, out, (long long)n);
   return check_launch("dropout_mask_kernel");
 }
 
@@ -452,12 +459,10 @@ extern "C" int ali_bce_logits(const float* logit, int32_t B, float target, float
 }
 
 extern "C" int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                        float eps, int32_t step, ali_stream_t stream) {
-  if (!p || !g || !m || !v || n <= 0 || step < 1) { set_error("ali_adam: bad argument"); return ALI_ERR_BAD_ARG; }
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+                        float eps, int32_t step, const int32_t* dev_step, float grad_scale, ali_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || (!dev_step && step < 1)) { set_error("ali_adam: bad argument"); return ALI_ERR_BAD_ARG; }
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 4)), dim3(kEwBlock), 0, ST(stream), p, g, m, v, (long long)n, lr, beta1, beta2,
-                     eps, (float)bc1, (float)sqrt(bc2));
+                     eps, (int)step, reinterpret_cast<const int*>(dev_step), grad_scale);
   return check_launch("adam_kernel");
 }
 

@@ -102,8 +102,11 @@ int ali_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, float* out, 
 /* out = x * mask[img, c]   (nn.Dropout2d forward and backward, mnist.py:99-134) */
 int ali_rowmask_mul(const float* x, const float* mask, float* out, int32_t B, int32_t rows_per_img, int32_t C,
                     ali_stream_t stream);
-/* counter-based Bernoulli(1-p)/(1-p) masks for production runs */
-int ali_dropout_mask(uint64_t seed, uint64_t offset, float p, float* out, int64_t n, ali_stream_t stream);
+/* counter-based Bernoulli(1-p)/(1-p) masks for production runs: draw i uses the key
+ * (seed, *dev_counter, offset + i).  dev_counter (device int64, may be NULL) lets a captured
+ * HIP graph produce fresh masks on every replay (the stepper bumps it once per iteration). */
+int ali_dropout_mask(uint64_t seed, uint64_t offset, const int64_t* dev_counter, float p, float* out, int64_t n,
+                     ali_stream_t stream);
 
 /* nn.BatchNorm2d in training / eval mode (mnist.py:111,114,118,122).
  * stats: per-channel batch mean / biased var of (mask ? x*mask : x), running
@@ -133,9 +136,10 @@ int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, fl
                    ali_stream_t stream);
 
 /* torch.optim.Adam step (mnist.py:176-179,230,236,241), no amsgrad / decay.
- * One launch over a flat parameter segment; `step` is the 1-based step count. */
+ * One launch over a flat parameter segment.  The 1-based step count is `step`, or *dev_step when
+ * dev_step != NULL (graph replays); the gradient is read as grad_scale * g (1/world for DP). */
 int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-             float eps, int32_t step, ali_stream_t stream);
+             float eps, int32_t step, const int32_t* dev_step, float grad_scale, ali_stream_t stream);
 
 /* Conditioning-plane assembly (mnist.py:24-29,46-55; audio_mnist.py:178-209):
  * out[b,h,w,0] = X[b,h,w]; out[..,1+j] = tanh(emb_j[idx_j[b]][src(h,w)]) for the

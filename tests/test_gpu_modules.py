@@ -207,3 +207,65 @@ def test_hip_library_is_loaded_and_mandatory():
     assert lib.ali_version() >= 1
     with open("/proc/self/maps") as f:
         assert "libali_hip.so" in f.read()
+
+
+def _stepper_setup(rescale=True, capture=False, bs=64):
+    from ali_hip.step import AliStepper
+    (Eo, Go, Do), (E, G, D), _, _, _ = paired_models("mnist", rescale=rescale)
+    for m in (Eo, Go, Do, E, G, D):
+        m.train()
+    x, a = orc.synth_morphomnist(3 * bs, seed=1)
+    stats = {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"}
+    batches = []
+    g = torch.Generator().manual_seed(123)
+    for i in range(3):
+        images, c = orc.mnist_scale_batch(x[i * bs:(i + 1) * bs], {k: v[i * bs:(i + 1) * bs] for k, v in a.items()},
+                                          stats)
+        batches.append((images, c, torch.randn(bs, 512, 1, 1, generator=g)))
+    return (Eo, Go, Do), (E, G, D), AliStepper(E, G, D, capture=capture), batches
+
+
+@pytest.mark.parametrize("rescale", [True, False])
+def test_hand_scheduled_stepper_vs_oracle(rescale):
+    """AliStepper (no autograd, wasted work skipped, flat Adam kernel) == the reference iteration."""
+    (Eo, Go, Do), (E, G, D), stepper, batches = _stepper_setup(rescale)
+    oe, od = orc.build_optimizers(Eo, Go, Do, "mnist")
+    for i, (images, c, z) in enumerate(batches):
+        tape = orc.MaskTape()
+        ro = orc.ali_step(Eo, Go, Do, oe, od, images, c, z, tape=tape)
+        rp = stepper.step(images.cuda(), to_dev(c), z.cuda(), masks=tape.masks)
+        tol = 1e-5 if i == 0 else 1e-3
+        for k in ("loss_eg", "loss_d_real", "loss_d_fake", "dg", "de"):
+            assert abs(rp[k].item() - ro[k]) <= tol * max(1.0, abs(ro[k])), (i, k, rp[k].item(), ro[k])
+    for nm, mo, mp in (("E", Eo, E), ("G", Go, G), ("D", Do, D)):
+        so = mo.state_dict()
+        for k, v in mp.state_dict().items():
+            if "num_batches" in k:
+                assert int(v) == int(so[k]), k
+            elif "running" in k:
+                close(v.float(), so[k].float(), 1e-3, f"{nm}.{k}")
+            else:
+                diff = (v.cpu().double() - so[k].double()).abs()
+                assert diff.max().item() <= 3 * 2.2e-4, (nm, k, diff.max().item())
+                assert diff.mean().item() <= 0.02 * 1e-4, (nm, k, diff.mean().item())
+
+
+def test_graph_captured_stepper_equals_eager():
+    """HIP-graph replay of the iteration == eager launches (device-side Adam step count and dropout counter)."""
+    import ali_hip
+    ali_hip.manual_seed(99)
+    _, (E1, G1, D1), eager, batches = _stepper_setup(capture=False)
+    ali_hip.manual_seed(99)
+    _, (E2, G2, D2), graphed, _ = _stepper_setup(capture=True)
+    outs = []
+    for images, c, z in batches:
+        r1 = eager.step(images.cuda(), to_dev(c), z.cuda())
+        r2 = graphed.step(images.cuda(), to_dev(c), z.cuda())
+        outs.append(({k: v.item() for k, v in r1.items()}, {k: v.item() for k, v in r2.items()}))
+    for r1, r2 in outs:
+        for k in r1:
+            assert r1[k] == r2[k], (k, r1[k], r2[k])
+    for (k, v1), (_, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
+        assert torch.equal(v1, v2), k
+    # Dropout masks differ between iterations (fresh counter every replay)
+    assert outs[0][0]["dg"] != outs[1][0]["dg"]
