@@ -50,6 +50,12 @@ def cpu_baseline(bs, budget_s=25.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:  # the GPU box exposes 256 logical CPUs but a cgroup quota of 16: use what we may actually run on
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     torch.set_num_threads(cores)
     torch.manual_seed(1)
     E, G, D = orc.build_models("mnist")

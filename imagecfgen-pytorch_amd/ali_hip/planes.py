@@ -24,6 +24,25 @@ def _src_index(H, W, device):
     return m
 
 
+def plane_to_table_grad(gp, idx_col, n_rows, H, W):
+    """gp [B, H*W] (gradient w.r.t. the pre-tanh plane) -> gradient of the [n_rows, 256] embedding table.
+    Deterministic (no atomics): nearest up-sampling is undone by a block sum (integer factors) or by a product
+    with the fixed 0/1 pixel->cell matrix, the per-class scatter by a product with the one-hot matrix."""
+    B = gp.shape[0]
+    if H % 16 == 0 and W % 16 == 0:
+        per_sample = gp.reshape(B, 16, H // 16, 16, W // 16).sum(dim=(2, 4)).reshape(B, 256)
+    else:
+        key = ("S", H, W, str(gp.device))
+        S = _MAPS.get(key)
+        if S is None:
+            S = torch.zeros(H * W, 256, device=gp.device)
+            S[torch.arange(H * W, device=gp.device), _src_index(H, W, gp.device)] = 1.0
+            _MAPS[key] = S
+        per_sample = gp.matmul(S)
+    onehot = (idx_col.reshape(B, 1) == torch.arange(n_rows, device=gp.device, dtype=idx_col.dtype).reshape(1, -1))
+    return onehot.float().t().matmul(per_sample)
+
+
 class PlanesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, idx, cont, cpad, *tables):
@@ -45,16 +64,13 @@ class PlanesFn(torch.autograd.Function):
         if ctx.n_cont and ctx.needs_input_grad[2]:
             gcont = g[..., 1 + ctx.n_emb:1 + ctx.n_emb + ctx.n_cont].sum(dim=(1, 2))
         gtabs = []
-        src = _src_index(H, W, g.device)
         for j in range(ctx.n_emb):
             if not ctx.needs_input_grad[4 + j]:
                 gtabs.append(None)
                 continue
             plane = out[..., 1 + j].reshape(B, H * W)
             gp = g[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)          # tanh'
-            per_sample = torch.zeros(B, 256, device=g.device).index_add_(1, src, gp)
-            gt = torch.zeros(ctx.table_rows[j], 256, device=g.device).index_add_(0, idx[:, j].long(), per_sample)
-            gtabs.append(gt)
+            gtabs.append(plane_to_table_grad(gp, idx[:, j], ctx.table_rows[j], H, W))
         return (gX, None, gcont, None) + tuple(gtabs)
 
 

@@ -110,7 +110,7 @@ class AliStepper:
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.capture = capture
         self._graph = None
-        self._static = None
+
         self.bn_buffers = [b for n_, b in D.named_buffers() if "running" in n_]
         self.iter_t = torch.zeros(1, dtype=torch.int64, device=self.opt_d.flat.device)
 
@@ -125,14 +125,12 @@ class AliStepper:
 
     def _plane_grads(self, g0, x0, idx, tables, dst):
         """Embedding-table gradients from the gradient of the assembled planes (tiny tensors)."""
-        from .planes import _src_index
+        from .planes import plane_to_table_grad
         B, H, W, _ = g0.shape
-        src = _src_index(H, W, g0.device)
         for j, t in enumerate(tables):
             plane = x0[..., 1 + j].reshape(B, H * W)
             gp = g0[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)
-            per_sample = torch.zeros(B, 256, device=g0.device).index_add_(1, src, gp)
-            dst[id(t)].zero_().index_add_(0, idx[:, j].long(), per_sample)
+            dst[id(t)].copy_(plane_to_table_grad(gp, idx[:, j], t.shape[0], H, W))
 
     def _g_input(self, z, onehots, cont):
         B = z.shape[0]
@@ -176,76 +174,88 @@ class AliStepper:
             torch.distributed.all_reduce(group.grad, group=self.pg)
         group.adam(1.0 / self.world)
 
-    # ------------------------------------------------------------------ the iteration
-    def _iteration(self, images, c, z, do_eg=True):
-        fam = self.family
+    # ------------------------------------------------------------------ the iteration, phase by phase
+    def _begin(self, images, c, z):
         B = images.shape[0]
         self.iter_t += 1
         _dropout.begin_iteration(self.iter_t)
-        idx, cont, onehots = fam.conditioning(c)
-        out = {}
-        zin = z.reshape(B, -1).float().contiguous()
-        if do_eg:
-            x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
-            ex, sE = chain_forward(self.pE, x0e, True, n_log, True)
-            x0d, _ = self._planes(images, idx, cont, fam.d_tables)
-            d_valid, sD1 = self._d_forward(x0d, n_log, ex, True)
-            gin, g_log = self._g_input(zin, onehots, cont)
-            gz, sG = chain_forward(self.pG, gin, True, g_log, True)
-            x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
-            d_fake, sD2 = self._d_forward(x0f, n_log, zin, True)
-            l1, gl1 = ops.bce_logits(d_valid, 0.0, 0.5)
-            l2, gl2 = ops.bce_logits(d_fake, 1.0, 0.5)
-            out["loss_eg"] = (l1[0] + l2[0]) / 2
-            # real branch: only the z-side path reaches E
-            _, g_ex = self._d_backward(sD1, gl1, False, False, True)
-            dst = self.opt_eg.grad_views
-            g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, True, True, dst)
-            self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
-            # fake branch: only the image path reaches G
-            g_x0f, _ = self._d_backward(sD2, gl2, False, True, False)
-            g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
-            g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst)
-            g_gin = g_gin.reshape(B, -1)
-            off = zin.shape[1]
-            for oh, t in zip(onehots, fam.g_tables):
-                dst[id(t)].copy_(oh.t().matmul(g_gin[:, off:off + 256]))
-                off += 256
-            del sE, sG, sD1, sD2
-            self._reduce_and_step(self.opt_eg)
-            self.pE.cache.refresh()
-            self.pG.cache.refresh()
-        # ---- D step a: real pair with the updated encoder
+        idx, cont, onehots = self.family.conditioning(c)
+        return {"images": images, "B": B, "idx": idx, "cont": cont, "onehots": onehots,
+                "zin": z.reshape(B, -1).float().contiguous(), "out": {}}
+
+    def _phase_eg(self, cx):
+        """E+G update (reference mnist.py:224-230)."""
+        fam, images, idx, cont, onehots, zin, B = (self.family, cx["images"], cx["idx"], cx["cont"], cx["onehots"],
+                                                   cx["zin"], cx["B"])
+        x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
+        ex, sE = chain_forward(self.pE, x0e, True, n_log, True)
+        x0d, _ = self._planes(images, idx, cont, fam.d_tables)
+        d_valid, sD1 = self._d_forward(x0d, n_log, ex, True)
+        gin, g_log = self._g_input(zin, onehots, cont)
+        gz, sG = chain_forward(self.pG, gin, True, g_log, True)
+        x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
+        d_fake, sD2 = self._d_forward(x0f, n_log, zin, True)
+        l1, gl1 = ops.bce_logits(d_valid, 0.0, 0.5)
+        l2, gl2 = ops.bce_logits(d_fake, 1.0, 0.5)
+        cx["out"]["loss_eg"] = (l1[0] + l2[0]) / 2
+        # real branch: only the z-side path (dxz -> dz) reaches E
+        _, g_ex = self._d_backward(sD1, gl1, False, False, True)
+        dst = self.opt_eg.grad_views
+        g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, True, True, dst)
+        self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
+        # fake branch: only the image path (dxz -> dx) reaches G
+        g_x0f, _ = self._d_backward(sD2, gl2, False, True, False)
+        g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
+        g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst)
+        g_gin = g_gin.reshape(B, -1)
+        off = zin.shape[1]
+        for oh, t in zip(onehots, fam.g_tables):
+            dst[id(t)].copy_(oh.t().matmul(g_gin[:, off:off + 256]))
+            off += 256
+        self._reduce_and_step(self.opt_eg)
+        self.pE.cache.refresh()
+        self.pG.cache.refresh()
+
+    def _phase_d_real(self, cx):
+        """D update on (x, E'(x)) (reference mnist.py:232-236); E' forward only."""
+        fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
         x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
         ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
         x0d, _ = self._planes(images, idx, cont, fam.d_tables)
         d_valid, sD = self._d_forward(x0d, n_log, ex, True)
         l, gl = ops.bce_logits(d_valid, 1.0, 1.0)
-        out["loss_d_real"] = l[0]
+        cx["out"]["loss_d_real"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False)
         self._plane_grads(g_x0, x0d, idx, fam.d_tables, self.opt_d.grad_views)
-        del sD
         self._reduce_and_step(self.opt_d)
         self._refresh_d()
-        # ---- D step b: fake pair with the updated generator
-        gin, g_log = self._g_input(zin, onehots, cont)
+        cx["ex"], cx["n_log"] = ex, n_log
+
+    def _phase_d_fake(self, cx):
+        """D update on (G'(z), z) (reference mnist.py:237-241); G' forward only."""
+        fam, idx, cont, zin = self.family, cx["idx"], cx["cont"], cx["zin"]
+        gin, g_log = self._g_input(zin, cx["onehots"], cont)
         gz, _ = chain_forward(self.pG, gin, True, g_log, False)
         x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
-        d_fake, sD = self._d_forward(x0f, n_log, zin, True)
+        d_fake, sD = self._d_forward(x0f, cx["n_log"], zin, True)
         l, gl = ops.bce_logits(d_fake, 0.0, 1.0)
-        out["loss_d_fake"] = l[0]
+        cx["out"]["loss_d_fake"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False)
         self._plane_grads(g_x0, x0f, idx, fam.d_tables, self.opt_d.grad_views)
-        del sD
         self._reduce_and_step(self.opt_d)
         self._refresh_d()
-        # ---- diagnostics (forward only, train mode; re-uses G'(z) and E'(x))
-        x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
-        dg, _ = self._d_forward(x0f, n_log, zin, False)
+        cx["gz"] = gz
+
+    def _phase_scores(self, cx):
+        """sigma(D(G(z),z)).mean(), sigma(D(x,E(x))).mean() (reference mnist.py:243-248): forward only, train mode,
+        re-using G'(z) and E'(x) of the D phases (the reference recomputes identical values)."""
+        fam, images, idx, cont, zin = self.family, cx["images"], cx["idx"], cx["cont"], cx["zin"]
+        x0f, _ = self._planes(cx["gz"], idx, cont, fam.d_tables)
+        dg, _ = self._d_forward(x0f, cx["n_log"], zin, False)
         x0d, _ = self._planes(images, idx, cont, fam.d_tables)
-        de, _ = self._d_forward(x0d, n_log, ex, False)
-        out["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
-        out["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
+        de, _ = self._d_forward(x0d, cx["n_log"], cx["ex"], False)
+        cx["out"]["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
+        cx["out"]["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
         if self.world > 1 and self.bn_buffers:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
             flat = torch.cat([b.reshape(-1) for b in self.bn_buffers])
@@ -255,7 +265,15 @@ class AliStepper:
             for b in self.bn_buffers:
                 b.copy_(flat[off:off + b.numel()].view_as(b))
                 off += b.numel()
-        return out
+
+    def _iteration(self, images, c, z, do_eg=True):
+        cx = self._begin(images, c, z)
+        if do_eg:
+            self._phase_eg(cx)
+        self._phase_d_real(cx)
+        self._phase_d_fake(cx)
+        self._phase_scores(cx)
+        return cx["out"]
 
     def _state_tensors(self):
         ts = [self.iter_t]
@@ -272,6 +290,35 @@ class AliStepper:
         for t, v in zip(self._state_tensors(), vals):
             t.copy_(v)
         self.opt_eg.steps, self.opt_d.steps = se, sd
+        for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
+            pl.cache.refresh()
+
+    def load_state(self, E_src, G_src, D_src, opt_e=None, opt_d=None):
+        """Adopt the weights / buffers of another (e.g. CPU, reference-trained) E, G, D and, optionally, the
+        exp_avg / exp_avg_sq / step of their torch.optim.Adam optimisers; kernel-layout copies are refreshed."""
+        for src, dst in ((E_src, self.E), (G_src, self.G), (D_src, self.D)):
+            sd = src.state_dict()
+            for k, v in dst.state_dict().items():
+                v.copy_(sd[k])
+        for group, opt, mods in ((self.opt_eg, opt_e, (E_src, G_src)), (self.opt_d, opt_d, (D_src,))):
+            if opt is None:
+                continue
+            src_params = [p for m in mods for p in m.parameters()]
+            off = 0
+            step = 0
+            for p_src, p_dst in zip(src_params, group.params):
+                st = opt.state.get(p_src, {})
+                n = p_dst.numel()
+                if st:
+                    group.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    group.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    step = int(st["step"])
+                else:
+                    group.m[off:off + n].zero_()
+                    group.v[off:off + n].zero_()
+                off += n
+            group.steps = step
+            group.step_t.fill_(step)
         for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
             pl.cache.refresh()
 

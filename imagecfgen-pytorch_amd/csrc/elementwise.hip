@@ -37,6 +37,12 @@ __global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __rest
   for (; i < n; i += step) gpre[i] = gy[i] * act_grad_from_output(y[i], act, slope);
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
 // ---- column sums: stage 1 writes [nblk][C] partials, stage 2 folds them ----
 // block = 256 threads as (256/CT) row lanes x CT channel lanes, CT = min(C,256) rounded to pow2 lanes
 __global__ void colsum_partial_kernel(const float* __restrict__ x, long long rows, int C, int ld,
@@ -63,12 +69,13 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, long long row
     __syncthreads();
   }
 }
+// one 64-lane wave per channel: lanes stride over the partial slabs, fixed-order wave reduction in double
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * C + c];
-  out[c] = (float)s;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[(long long)b * C + c];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 __global__ void rowmask_mul_kernel(const float* __restrict__ x, const float* __restrict__ mask,
@@ -140,15 +147,17 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblk, 
                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                       float momentum, float eps, int training, float* __restrict__ mean_out,
                                       float* __restrict__ invstd_out, float* __restrict__ sc, float* __restrict__ sh) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;   // one wave per channel
   float mean, var;
   if (training) {
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
       s1 += (double)part[((long long)b * 2 + 0) * C + c];
       s2 += (double)part[((long long)b * 2 + 1) * C + c];
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x != 0) return;
     const double m = s1 / (double)count;
     double v = s2 / (double)count - m * m;
     if (v < 0.0) v = 0.0;
@@ -160,6 +169,7 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblk, 
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
   } else {
+    if (threadIdx.x != 0) return;
     mean = running_mean[c];
     var = running_var[c];
   }
@@ -227,15 +237,18 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
 }
 __global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;   // one wave per channel
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = threadIdx.x; b < nblk; b += 64) {
     s1 += (double)part[((long long)b * 2 + 0) * C + c];
     s2 += (double)part[((long long)b * 2 + 1) * C + c];
   }
-  dgamma[c] = (float)s1;
-  dbeta[c] = (float)s2;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (threadIdx.x == 0) {
+    dgamma[c] = (float)s1;
+    dbeta[c] = (float)s2;
+  }
 }
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                     const float* __restrict__ mask_in, const float* __restrict__ mask_pre,
@@ -366,7 +379,7 @@ static int reduce_blocks(long long rows, int C) {
   while (lanes_c < cw) lanes_c <<= 1;
   const int lanes_r = kEwBlock / lanes_c;
   long long nb = (rows + (long long)lanes_r * 8 - 1) / ((long long)lanes_r * 8);
-  if (nb > 1024) nb = 1024;
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -378,7 +391,7 @@ extern "C" int ali_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, f
   if (!ws || ws_bytes < (size_t)nb * C * sizeof(float)) { set_error("ali_colsum: workspace too small"); return ALI_ERR_WORKSPACE; }
   float* part = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, (long long)rows, C, ld, part);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, ST(stream), part, nb, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, out);
   return check_launch("colsum");
 }
 
@@ -413,7 +426,7 @@ extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_
   float* part = reinterpret_cast<float*>(ws);
   if (training)
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, mask, rows, rows_per_img, C, part);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(256), 0, ST(stream), part, nb, C, rows, gamma, beta,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, rows, gamma, beta,
                      running_mean, running_var, momentum, eps, training, mean, invstd, sc, sh);
   return check_launch("bn_stats");
 }
@@ -442,7 +455,7 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
   float* part = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean, invstd,
                      rows, rows_per_img, C, part);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(256), 0, ST(stream), part, nb, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, dgamma, dbeta);
   if (gx) {
     const long long n = rows * C;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean,
