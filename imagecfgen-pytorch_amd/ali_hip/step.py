@@ -24,6 +24,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
+from . import dp
 from . import dropout as _dropout
 from . import ops
 from .chain import chain_backward, chain_forward, get_plan
@@ -171,7 +172,7 @@ class AliStepper:
     def _reduce_and_step(self, group: FlatGroup):
         """DP: one RCCL all-reduce(sum) of the flat gradient; the 1/world average is folded into Adam."""
         if self.world > 1:
-            torch.distributed.all_reduce(group.grad, group=self.pg)
+            dp.allreduce_sum_(group.grad, self.pg)
         group.adam(1.0 / self.world)
 
     # ------------------------------------------------------------------ the iteration, phase by phase
@@ -256,15 +257,9 @@ class AliStepper:
         de, _ = self._d_forward(x0d, cx["n_log"], cx["ex"], False)
         cx["out"]["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
         cx["out"]["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
-        if self.world > 1 and self.bn_buffers:
+        if self.world > 1:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
-            flat = torch.cat([b.reshape(-1) for b in self.bn_buffers])
-            torch.distributed.all_reduce(flat, group=self.pg)
-            flat.mul_(1.0 / self.world)
-            off = 0
-            for b in self.bn_buffers:
-                b.copy_(flat[off:off + b.numel()].view_as(b))
-                off += b.numel()
+            dp.average_buffers_(self.bn_buffers, self.pg)
 
     def _iteration(self, images, c, z, do_eg=True):
         cx = self._begin(images, c, z)

@@ -124,10 +124,16 @@ def wgan_loss_it(disc, x_real, x_fake, penalty_weight=10.0):
 # ----------------------------------------------------------------------------
 # new: the ALI iteration as a function (the reference inlines it, mnist.py:224-248)
 # ----------------------------------------------------------------------------
-def ali_step(E, G, D, optimizer_E, optimizer_D, images, c, z, do_eg=True, gan_loss=None):
+def _group_params(opt):
+    return [p for g in opt.param_groups for p in g["params"]]
+
+
+def ali_step(E, G, D, optimizer_E, optimizer_D, images, c, z, do_eg=True, gan_loss=None, grad_sync=None):
     """One ALI/BiGAN iteration exactly as the reference executes it: E+G update,
     D update on (x, E(x)), D update on (G(z), z), then the two diagnostic scores.
     Works for any device; on CUDA the modules dispatch to the HIP kernels.
+    ``grad_sync(params)`` (e.g. ``ali_hip.dp.GradSync``) is called after every backward, before the optimiser
+    step, to average gradients across data-parallel replicas.
     Returns dict(loss_eg, loss_d_real, loss_d_fake, dg, de) of 0-d tensors (no host sync)."""
     gan_loss = gan_loss or nn.BCEWithLogitsLoss()
     n = images.size(0)
@@ -140,15 +146,21 @@ def ali_step(E, G, D, optimizer_E, optimizer_D, images, c, z, do_eg=True, gan_lo
         d_fake = D(G(z, c), z, c)
         loss_eg = (gan_loss(d_valid, fake) + gan_loss(d_fake, valid)) / 2
         loss_eg.backward()
+        if grad_sync is not None:
+            grad_sync(_group_params(optimizer_E))
         optimizer_E.step()
         out["loss_eg"] = loss_eg.detach()
     optimizer_D.zero_grad()
     loss_dr = gan_loss(D(images, E(images, c), c), valid)
     loss_dr.backward()
+    if grad_sync is not None:
+        grad_sync(_group_params(optimizer_D))
     optimizer_D.step()
     optimizer_D.zero_grad()
     loss_df = gan_loss(D(G(z, c), z, c), fake)
     loss_df.backward()
+    if grad_sync is not None:
+        grad_sync(_group_params(optimizer_D))
     optimizer_D.step()
     gz = G(z, c).detach()
     ex = E(images, c).detach()
