@@ -29,3 +29,12 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fixed_cpu_threads():
+    """Bit-exact agreement with the golden fixtures needs the thread count they were generated with (8):
+    oneDNN / OpenMP reduction order depends on it."""
+    import torch
+    torch.set_num_threads(8)
+    yield
