@@ -53,6 +53,11 @@ SIGNATURES = {
                            c_int32, c_void_p, c_float, c_void_p]),
     "ali_assemble_planes": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_int32, c_void_p,
                                       c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ali_tconv1_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_float, c_void_p]),
+    "ali_tconv1_dgrad": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p] + [c_int32] * 7
+                         + [c_void_p]),
+    "ali_tconv1_wgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int64, c_int64]
+                         + [c_int32] * 7 + [c_void_p, c_size_t, c_void_p]),
     "ali_last_error": (c_char_p, []),
     "ali_version": (c_int32, []),
 }

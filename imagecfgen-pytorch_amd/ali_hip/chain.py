@@ -203,6 +203,21 @@ def _geom(st: Stage, xin_shape, out_shape):
     return ops.geom(B, 1, 1, C, 1, 1, P * Q * K, 1, 1, 1, 0)
 
 
+def _is_tconv1(st: Stage, cin_stride: int) -> bool:
+    """ConvTranspose2d(C -> 1), stride 1, no output padding: served by the direct one-channel kernels."""
+    m = st.mod
+    return (st.kind == "convT" and m.out_channels == 1 and m.stride[0] == 1 and m.output_padding[0] == 0
+            and m.kernel_size[0] <= 5 and cin_stride in (32, 64, 128, 256) and st.act in (ACT_NONE, ACT_LEAKY, ACT_TANH))
+
+
+def _first_conv_direct(st: Stage, c_in_log: int) -> bool:
+    """First Conv2d of a stack (<= 8 real input channels, stride 1): per-channel direct weight gradient and
+    single-plane data gradient (ali_tconv1_*)."""
+    m = st.mod
+    return (st.kind == "conv" and m.stride[0] == 1 and c_in_log <= 8 and m.out_channels in (32, 64, 128, 256)
+            and m.kernel_size[0] <= 5)
+
+
 def _pad_mask(mask, cpad):
     if mask.shape[1] == cpad:
         return mask
@@ -252,7 +267,11 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
         g = _geom(st, (B, H, W, Cp), out_shape)
         y = torch.empty(out_shape, dtype=torch.float32, device=cur.device)
         ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope)
-        if st.kind == "convT":
+        if _is_tconv1(st, Cp):
+            m = st.mod
+            ops.tconv1_fwd(t, plan.packed(st, "fwd", Cp), plan.packed_bias(st), y, B, H, W, Cp, m.kernel_size[0],
+                           m.kernel_size[1], m.padding[0], 1, st.act, st.slope)
+        elif st.kind == "convT":
             ops.conv_bwd_data(g, t, plan.packed(st, "fwd", Cp), y, ep)
         else:
             ops.conv_fwd(g, t, plan.packed(st, "fwd", Cp), y, ep)
@@ -265,9 +284,12 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
 
 
 def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True,
-                   grad_dst=None):
+                   grad_dst=None, gx_planes=None):
     """Returns (gx or None, {param tensor id -> grad}).  ``grad_dst`` optionally maps id(param) to a
-    preallocated destination (a view of a flat gradient buffer) that the kernels write directly."""
+    preallocated destination (a view of a flat gradient buffer) that the kernels write directly.
+    ``gx_planes`` (hand-scheduled step only): instead of the full input gradient return only these input
+    channels of it, as a [B,H,W,len(gx_planes)] tensor -- the first layer's data gradient is consumed one plane
+    at a time (image plane towards G, embedding plane towards the digit table)."""
     grads = {}
     grad_dst = grad_dst or {}
     n = len(plan.stages)
@@ -297,9 +319,18 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                 else:
                     grads[id(m.bias)] = ops.colsum(rows_out, K, K, g_pre, out=grad_dst.get(id(m.bias)))
             dw = grad_dst[id(m.weight)] if id(m.weight) in grad_dst else torch.empty_like(m.weight)
-            if st.kind == "conv":
+            if st.kind == "conv" and i == 0 and _first_conv_direct(st, c_in_log):
+                T = m.kernel_size[0] * m.kernel_size[1]
+                # dW[k][c][tap] = sum big=g_pre[..,k] * small=t[..,c], all input channels in one launch
+                ops.tconv1_wgrad(g_pre, sv.t, Cp, c_in_log, dw, c_in_log * T, 1, T, B, P, Q, K,
+                                 m.kernel_size[0], m.kernel_size[1], m.padding[0])
+            elif st.kind == "conv":
                 T = m.kernel_size[0] * m.kernel_size[1]
                 ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1)
+            elif _is_tconv1(st, Cp):
+                T = m.kernel_size[0] * m.kernel_size[1]
+                ops.tconv1_wgrad(sv.t, g_pre, 1, 1, dw, T, 1, 0, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1],
+                                 m.padding[0])
             elif st.kind == "convT":
                 T = m.kernel_size[0] * m.kernel_size[1]
                 # gathered operand = convT output-grad (channels K), dense = convT input (channels Cp)
@@ -316,6 +347,17 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                     ops.pack_weights(tmp, dw, Cc, T, I, I, I, Cc * I, 1)
             grads[id(m.weight)] = dw
         # ---- data gradient, folded with what sits between y_{i-1} and this conv
+        if i == 0 and gx_planes is not None and sv.bn is None and _first_conv_direct(st, c_in_log):
+            planes = torch.empty(B, H, W, len(gx_planes), dtype=torch.float32, device=gy.device)
+            wd = plan.packed(st, "dgrad", Cp)                  # [Cpad][T][K]: row c is the [T][K] filter of plane c
+            for j, c in enumerate(gx_planes):
+                ops.tconv1_fwd(g_pre, wd[c], None, planes[..., j], B, P, Q, K, m.kernel_size[0], m.kernel_size[1],
+                               m.padding[0], len(gx_planes), ACT_NONE, 0.0)
+            if sv.mask is not None:
+                cols = torch.cat([sv.mask[:, c:c + 1] for c in gx_planes], dim=1)   # slices only: graph-capture safe
+                planes = planes * cols.reshape(B, 1, 1, -1)
+            gx = planes
+            break
         if i == 0 and not need_gx and sv.bn is None:
             break
         pact, pslope = (prev.act, prev.slope) if prev is not None else (ACT_NONE, 0.0)
@@ -324,7 +366,10 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             ep = ops.epilogue(mask=sv.mask, dact_y=sv.x_in if pact != ACT_NONE else None, dact=pact, dslope=pslope)
         else:
             ep = ops.epilogue()
-        if st.kind == "convT":
+        if _is_tconv1(st, Cp) and sv.bn is None and sv.mask is None:
+            ops.tconv1_dgrad(g_pre, 1, plan.packed(st, "fwd", Cp), sv.x_in if pact != ACT_NONE else None, pact, pslope,
+                             gt, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1], m.padding[0])
+        elif st.kind == "convT":
             ops.conv_fwd(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)
         else:
             ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)

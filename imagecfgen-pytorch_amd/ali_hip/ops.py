@@ -71,12 +71,22 @@ class KernelProfile:
     def summary(self):
         torch.cuda.synchronize()
         fam = {}
-        for name, flops, e0, e1 in self.records:
+        for name, flops, e0, e1, _ in self.records:
             f = fam.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
             f["launches"] += 1
             f["flops"] += flops
             f["ms"] += e0.elapsed_time(e1)
         return fam
+
+    def by_shape(self):
+        torch.cuda.synchronize()
+        tab = {}
+        for name, flops, e0, e1, desc in self.records:
+            f = tab.setdefault((name,) + desc, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            f["launches"] += 1
+            f["flops"] += flops
+            f["ms"] += e0.elapsed_time(e1)
+        return tab
 
 
 _PROFILE = None
@@ -91,6 +101,7 @@ class _Timed:
     def __init__(self, name, g: AliConvGeom):
         self.name = name
         self.flops = 2.0 * g.B * g.P * g.Q * g.K * g.C * g.R * g.S
+        self.desc = (g.B, g.H, g.W, g.C, g.P, g.Q, g.K, g.R, g.stride, g.pad)
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -101,7 +112,23 @@ class _Timed:
     def __exit__(self, *exc):
         if _PROFILE is not None:
             self.e1.record()
-            _PROFILE.records.append((self.name, self.flops, self.e0, self.e1))
+            _PROFILE.records.append((self.name, self.flops, self.e0, self.e1, self.desc))
+
+
+class _TimedRaw:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.e1.record()
+            _PROFILE.records.append((self.name, self.flops, self.e0, self.e1, (0,) * 10))
 
 
 def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
@@ -116,7 +143,7 @@ def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
 def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
     lib = _lib.load()
     ws = workspace(dy.device)
-    with _Timed("gconv", g):
+    with _Timed("gconv_t", g):
         _lib.check(lib.ali_conv_bwd_data(byref(g), _chk(dy, "dy"), _chk(w_packed, "w"), _chk(dx, "dx"), byref(ep),
                                          c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
     return dx
@@ -130,6 +157,40 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
                                            s_dc, s_gc, s_tap, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
                    "ali_conv_bwd_weight")
     return dst
+
+
+def _ptr(t):
+    """raw pointer of a (possibly strided) fp32 CUDA view"""
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise ValueError("need an fp32 CUDA tensor")
+    return c_void_p(t.data_ptr())
+
+
+def tconv1_fwd(big, w_tk, bias, out, B, P, Q, K, R, S, pad, ostride, act, slope):
+    lib = _lib.load()
+    with _TimedRaw("tconv1_fwd", 2.0 * B * P * Q * K * R * S):
+        _lib.check(lib.ali_tconv1_fwd(_chk(big, "big"), _chk(w_tk, "w"), None if bias is None else _ptr(bias),
+                                      _ptr(out), B, P, Q, K, R, S, pad, ostride, act, slope, _stream()),
+                   "ali_tconv1_fwd")
+    return out
+
+
+def tconv1_dgrad(small, sstride, w_tk, dact_y, dact, dslope, gbig, B, P, Q, K, R, S, pad):
+    lib = _lib.load()
+    with _TimedRaw("tconv1_dgrad", 2.0 * B * P * Q * K * R * S):
+        _lib.check(lib.ali_tconv1_dgrad(_ptr(small), sstride, _chk(w_tk, "w"), _opt(dact_y), dact, dslope,
+                                        _chk(gbig, "gbig"), B, P, Q, K, R, S, pad, _stream()), "ali_tconv1_dgrad")
+    return gbig
+
+
+def tconv1_wgrad(big, small, sstride, nc, dw, s_k, s_tap, s_c, B, P, Q, K, R, S, pad):
+    lib = _lib.load()
+    ws = workspace(big.device)
+    with _TimedRaw("tconv1_wgrad", 2.0 * B * P * Q * K * R * S * nc):
+        _lib.check(lib.ali_tconv1_wgrad(_chk(big, "big"), _ptr(small), sstride, nc, _ptr(dw), s_k, s_tap, s_c, B, P,
+                                        Q, K, R, S, pad, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                   "ali_tconv1_wgrad")
+    return dw
 
 
 def pack_weights(src, dst, N, T, C, Cpad, s_n, s_tap, s_c):

@@ -114,6 +114,7 @@ class AliStepper:
 
         self.bn_buffers = [b for n_, b in D.named_buffers() if "running" in n_]
         self.iter_t = torch.zeros(1, dtype=torch.int64, device=self.opt_d.flat.device)
+        self._emb_planes = tuple(range(1, 1 + len(self.family.d_tables)))
 
     # ------------------------------------------------------------------ pieces
     def _planes(self, X, idx, cont, tables):
@@ -125,12 +126,14 @@ class AliStepper:
         return out, n_log
 
     def _plane_grads(self, g0, x0, idx, tables, dst):
-        """Embedding-table gradients from the gradient of the assembled planes (tiny tensors)."""
+        """Embedding-table gradients from the gradient of the assembled planes (tiny tensors).  ``g0`` is either the
+        full input gradient [B,H,W,Cpad] or only its embedding planes [B,H,W,len(tables)]."""
         from .planes import plane_to_table_grad
-        B, H, W, _ = g0.shape
+        B, H, W, C = g0.shape
+        gofs = 0 if C == len(tables) else 1
         for j, t in enumerate(tables):
             plane = x0[..., 1 + j].reshape(B, H * W)
-            gp = g0[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)
+            gp = g0[..., gofs + j].reshape(B, H * W) * (1 - plane * plane)
             dst[id(t)].copy_(plane_to_table_grad(gp, idx[:, j], t.shape[0], H, W))
 
     def _g_input(self, z, onehots, cont):
@@ -139,7 +142,7 @@ class AliStepper:
         if cont is not None:
             feats.append(cont)
         n_log = sum(f.shape[1] for f in feats)
-        pad = (-n_log) % 4
+        pad = (-n_log) % 32          # channel stride % 32 == 0 -> uniform-tap fast path of the GEMM kernel
         if pad:
             feats.append(torch.zeros(B, pad, device=z.device))
         return torch.cat(feats, dim=1).reshape(B, 1, 1, n_log + pad), n_log
@@ -152,7 +155,7 @@ class AliStepper:
         logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save)
         return logit.reshape(B, 1), (s_dx, s_dz, s_dxz, dx.shape[-1], n_log)
 
-    def _d_backward(self, saved, glogit, need_params, need_x, need_z):
+    def _d_backward(self, saved, glogit, need_params, need_x, need_z, planes=None):
         s_dx, s_dz, s_dxz, n_dx, n_log = saved
         B = glogit.shape[0]
         dst = self.opt_d.grad_views if need_params else None
@@ -162,7 +165,7 @@ class AliStepper:
         gx0 = gz = None
         if need_params or need_x:
             gx0, _ = chain_backward(self.pDx, s_dx, gjoint[:, :n_dx].contiguous().reshape(B, 1, 1, n_dx), n_log,
-                                    need_x, need_params, dst)
+                                    need_x, need_params, dst, gx_planes=planes if need_x else None)
         if need_params or need_z:
             nz = gjoint.shape[1] - n_dx
             gz, _ = chain_backward(self.pDz, s_dz, gjoint[:, n_dx:].contiguous().reshape(B, 1, 1, nz), nz, need_z,
@@ -205,7 +208,7 @@ class AliStepper:
         g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, True, True, dst)
         self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
         # fake branch: only the image path (dxz -> dx) reaches G
-        g_x0f, _ = self._d_backward(sD2, gl2, False, True, False)
+        g_x0f, _ = self._d_backward(sD2, gl2, False, True, False, planes=(0,))
         g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
         g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst)
         g_gin = g_gin.reshape(B, -1)
@@ -226,7 +229,7 @@ class AliStepper:
         d_valid, sD = self._d_forward(x0d, n_log, ex, True)
         l, gl = ops.bce_logits(d_valid, 1.0, 1.0)
         cx["out"]["loss_d_real"] = l[0]
-        g_x0, _ = self._d_backward(sD, gl, True, True, False)
+        g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0d, idx, fam.d_tables, self.opt_d.grad_views)
         self._reduce_and_step(self.opt_d)
         self._refresh_d()
@@ -241,7 +244,7 @@ class AliStepper:
         d_fake, sD = self._d_forward(x0f, cx["n_log"], zin, True)
         l, gl = ops.bce_logits(d_fake, 0.0, 1.0)
         cx["out"]["loss_d_fake"] = l[0]
-        g_x0, _ = self._d_backward(sD, gl, True, True, False)
+        g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0f, idx, fam.d_tables, self.opt_d.grad_views)
         self._reduce_and_step(self.opt_d)
         self._refresh_d()

@@ -13,11 +13,27 @@
 // contiguous direction of both the NHWC activation and the packed weight.
 //
 // Tile: 256 threads = 4 waves; BM x BN x 32, double-buffered LDS ([row][k], rows
-// padded to 36 floats => conflict-free ds_read_b128), one barrier per k-tile,
-// global->register prefetch of tile k+1 issued before the MFMAs of tile k.
+// padded to 36 floats => conflict-free ds_read_b128).
+//
+// What shaped the main loop (measured on MI355X, scratch/ub/mfma_overlap.hip and
+// rocprofv3 SQ counters): v_mfma_f32_32x32x2_f32 occupies the SIMD for 64 cycles and
+// shares the vector issue path -- a VALU instruction is NEVER hidden behind it (each
+// costs its full ~4 cycles, also across the two waves of a SIMD), while LDS, vector
+// memory and scalar instructions issued right behind an MFMA are.  So the loop
+//   * keeps VALU work per k-tile minimal: gathers are buffer loads (32-bit offset,
+//     hardware range check instead of selects; a dead lane gets an out-of-range
+//     offset and reads 0), tap validity is a per-row bit mask built once, the tap of a
+//     k-tile is block-uniform (channel stride % 32 == 0) and its constants come from
+//     LDS one iteration ahead: no division, no scalar-memory load, no branch;
+//   * slices everything that CAN hide (LDS fragment reads, LDS tile writes, global
+//     gathers) into single instructions placed behind individual MFMAs.
+// Layers whose channel stride is not a multiple of 32 (first layers) take a simpler
+// generic loop.
 #include "ali_common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace ali {
 
@@ -32,14 +48,17 @@ const char* get_error() { return g_err; }
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // 36 floats = 144 B rows: 16-B aligned, b128 conflict-free
+constexpr int kMaxGrid = 5;  // taps form a product grid nr x ns (<= 5 x 5)
 
+// Taps of one phase are the product {ir} x {is}: input pixel = (qh*mult + dh[ir], qw*mult + dw[is]),
+// weight tap = wr[ir]*S + ws[is]; tap index tp = ir*ns + is.
 struct Phase {
-  int Hq, Wq;          // extent of this phase's output sub-grid
-  int oh0, ow0, ostep; // output pixel = (oh0 + qh*ostep, ow0 + qw*ostep)
-  int mult;            // input pixel  = (qh*mult + dh, qw*mult + dw)
-  int ntaps, tile0, M; // taps, first M-tile, rows in this phase
-  signed char dh[kMaxTaps], dw[kMaxTaps];
-  unsigned char wt[kMaxTaps];
+  int Hq, Wq;           // extent of this phase's output sub-grid
+  int oh0, ow0, ostep;  // output pixel = (oh0 + qh*ostep, ow0 + qw*ostep)
+  int mult;
+  int nr, ns, M, tile0, pixmajor;
+  signed char dh[kMaxGrid], dw[kMaxGrid];
+  unsigned char wr[kMaxGrid], ws[kMaxGrid];
 };
 
 struct GDesc {
@@ -50,24 +69,40 @@ struct GDesc {
   AliEpilogue ep;
   int B, Hin, Win, Cin;
   int Hout, Wout, Cout, ldo;
-  int ldw;
+  int ldw, S;          // weight row stride (floats), kernel width (taps per kernel row)
   int nphase, splitk, kt_per_split;
+  unsigned in_bytes, w_bytes;
   long long out_elems;
   Phase ph[4];
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC>
-__global__ __launch_bounds__(256) void gconv_kernel(const GDesc d) {
+__device__ __attribute__((aligned(64))) float g_zero[16];  // generic path: dead lanes read zeros from here
+
+// q = m / dv, r = m % dv for 0 <= m < 2^24 (float reciprocal + one correction step)
+__device__ __forceinline__ void fast_divmod(int m, int dv, float rcp, int& q, int& r) {
+  q = (int)((float)m * rcp);
+  r = m - q * dv;
+  if (r < 0) { --q; r += dv; }
+  else if (r >= dv) { ++q; r -= dv; }
+}
+
+// MODE 0: scalar gathers (channel stride % 4 != 0); 1: 16-byte gathers, tap per thread; 2: uniform-tap fast path
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+__global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int AP = BM / 32, BP = BN / 32;  // float4 loads per thread per tile
+  constexpr int AP = BM / 32, BP = BN / 32;  // 16-byte gathers per thread per k-tile
+  constexpr int NL = AP + BP;
+  constexpr int NMF = 16 * TM * TN;          // MFMAs per wave per k-tile
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
   __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
-  __shared__ long long s_rowoff[BM];
+  __shared__ int s_rowoff[BM];  // element offset of the row's output pixel (host guarantees < 2^31), -1 = none
   __shared__ int s_rowimg[BM];
-  __shared__ int s_tap[kMaxTaps];  // dh | dw<<8 | wt<<16
+  __shared__ int s_tap[kMaxTaps];                                  // dh | dw<<8 | wt<<16 (generic path)
+  __shared__ __attribute__((aligned(16))) int s_live[kMaxTaps][4]; // per live tap {doff, woff, tap bit, 0} (bytes)
+  __shared__ unsigned s_tapmask;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -81,111 +116,69 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d) {
   const int m0 = ((int)blockIdx.x - P.tile0) * BM;
   const int n0 = blockIdx.y * BN;
   const int Cin = d.Cin, Hin = d.Hin, Win = d.Win;
-  const int Ktot = P.ntaps * Cin;
-  const int nkt = (Ktot + BK - 1) / BK;
-  const int kt_begin = blockIdx.z * d.kt_per_split;
-  const int kt_end = min(nkt, kt_begin + d.kt_per_split);
+  const int ntaps = P.nr * P.ns;
 
   if (t < kMaxTaps) {
     int v = 0;
-    if (t < P.ntaps) v = (P.dh[t] & 0xff) | ((P.dw[t] & 0xff) << 8) | ((int)P.wt[t] << 16);
+    if (t < ntaps) {
+      const int ir = t / P.ns, is = t - ir * P.ns;
+      v = (P.dh[ir] & 0xff) | ((P.dw[is] & 0xff) << 8) | (((int)P.wr[ir] * d.S + (int)P.ws[is]) << 16);
+    }
     s_tap[t] = v;
   }
+  if (t == 0) s_tapmask = 0u;
+
+  const float rW = 1.0f / (float)P.Wq, rH = 1.0f / (float)P.Hq, rB = 1.0f / (float)d.B;
+  auto decode = [&](int m, int& img, int& qh, int& qw) {
+    if (P.pixmajor) {
+      int pix;
+      fast_divmod(m, d.B, rB, pix, img);
+      fast_divmod(pix, P.Wq, rW, qh, qw);
+    } else {
+      int t2;
+      fast_divmod(m, P.Wq, rW, t2, qw);
+      fast_divmod(t2, P.Hq, rH, img, qh);
+    }
+  };
   for (int r = t; r < BM; r += 256) {
-    int m = m0 + r;
-    long long off = -1;
-    int img = 0;
+    const int m = m0 + r;
+    int off = -1, img = 0;
     if (m < P.M) {
-      int qw = m % P.Wq;
-      int t2 = m / P.Wq;
-      int qh = t2 % P.Hq;
-      img = t2 / P.Hq;
-      off = ((long long)(img * d.Hout + P.oh0 + qh * P.ostep) * d.Wout + (P.ow0 + qw * P.ostep)) * d.ldo;
+      int qh, qw;
+      decode(m, img, qh, qw);
+      off = ((img * d.Hout + P.oh0 + qh * P.ostep) * d.Wout + (P.ow0 + qw * P.ostep)) * d.ldo;
     }
     s_rowoff[r] = off;
     s_rowimg[r] = img;
   }
 
-  // per-thread gather rows
+  // ---- per-thread gather rows: element offset of the row's base pixel and a bit mask of the taps that hit the input
   const int c4 = t & 7;
   const int r0 = t >> 3;
-  long long abase[AP];
-  int aih[AP], aiw[AP];
-  bool avalid[AP];
+  int aoff[AP], aih[AP], aiw[AP];
+  unsigned amask[AP];
+  unsigned blockmask = 0u;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    int m = m0 + r0 + 32 * i;
-    avalid[i] = m < P.M;
-    int mm = avalid[i] ? m : 0;
-    int qw = mm % P.Wq;
-    int t2 = mm / P.Wq;
-    int qh = t2 % P.Hq;
-    int img = t2 / P.Hq;
+    const int m = m0 + r0 + 32 * i;
+    const bool valid = m < P.M;
+    int qw, qh, img;
+    decode(valid ? m : 0, img, qh, qw);
     aih[i] = qh * P.mult;
     aiw[i] = qw * P.mult;
-    abase[i] = ((long long)(img * Hin + aih[i]) * Win + aiw[i]) * Cin;
+    aoff[i] = ((img * Hin + aih[i]) * Win + aiw[i]) * Cin;
+    unsigned wbits = 0u, mk = 0u;
+    for (int is = 0; is < P.ns; ++is)
+      if ((unsigned)(aiw[i] + P.dw[is]) < (unsigned)Win) wbits |= 1u << is;
+    for (int ir = 0; ir < P.nr; ++ir)
+      if ((unsigned)(aih[i] + P.dh[ir]) < (unsigned)Hin) mk |= wbits << (ir * P.ns);
+    amask[i] = valid ? mk : 0u;
+    blockmask |= amask[i];
   }
   __syncthreads();
-
-  f32x4 ra[AP], rb[BP];
-  auto load_tile = [&](int kt) {
-    const int kflat = kt * BK + c4 * 4;
-    if (VEC) {
-      const bool kvalid = kflat < Ktot;
-      const int tap = kvalid ? kflat / Cin : 0;
-      const int c = kflat - tap * Cin;
-      const int tv = s_tap[tap];
-      const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
-      const long long doff = (long long)(dh * Win + dw) * Cin + c;
-#pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        const int ih = aih[i] + dh, iw = aiw[i] + dw;
-        const bool ok = kvalid && avalid[i] && (unsigned)ih < (unsigned)Hin && (unsigned)iw < (unsigned)Win;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(d.in + abase[i] + doff);
-        ra[i] = v;
-      }
-      const long long woff = (long long)wt * Cin + c;
-#pragma unroll
-      for (int j = 0; j < BP; ++j) {
-        const int n = n0 + r0 + 32 * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kvalid && n < d.Cout) v = *reinterpret_cast<const f32x4*>(d.w + (long long)n * d.ldw + woff);
-        rb[j] = v;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kf = kflat + e;
-        const bool kvalid = kf < Ktot;
-        const int tap = kvalid ? kf / Cin : 0;
-        const int c = kf - tap * Cin;
-        const int tv = s_tap[tap];
-        const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
-        const long long doff = (long long)(dh * Win + dw) * Cin + c;
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-          const int ih = aih[i] + dh, iw = aiw[i] + dw;
-          const bool ok = kvalid && avalid[i] && (unsigned)ih < (unsigned)Hin && (unsigned)iw < (unsigned)Win;
-          ra[i][e] = ok ? d.in[abase[i] + doff] : 0.f;
-        }
-        const long long woff = (long long)wt * Cin + c;
-#pragma unroll
-        for (int j = 0; j < BP; ++j) {
-          const int n = n0 + r0 + 32 * j;
-          rb[j][e] = (kvalid && n < d.Cout) ? d.w[(long long)n * d.ldw + woff] : 0.f;
-        }
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AP; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = ra[i];
-#pragma unroll
-    for (int j = 0; j < BP; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * j) * LDK + c4 * 4]) = rb[j];
-  };
+  if (c4 == 0 && blockmask) atomicOr(&s_tapmask, blockmask);
+  __syncthreads();
+  const unsigned tapmask = s_tapmask;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -195,64 +188,304 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
+  f32x4 ra[AP], rb[BP];
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * j) * LDK + c4 * 4]) = rb[j];
+  };
+  const int lrow = lane & 31, lh = lane >> 5;
+  const float* Ab = &As[0][(wm * WM + lrow) * LDK + lh * 4];
+  const float* Bb = &Bs[0][(wn * WN + lrow) * LDK + lh * 4];
+  f32x4 fa[2][TM], fb[2][TN];
+
+  if (MODE == 2) {
+    // ================= uniform-tap fast path =================
+    // live taps, compacted: {byte offset into the activation, byte offset into the weight row, tap bit}
+    if (t < ntaps && ((tapmask >> t) & 1u)) {
+      const int pos = __popc(tapmask & ((1u << t) - 1u));
+      const int tv = s_tap[t];
+      const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
+      s_live[pos][0] = ((dh * Win + dw) * Cin) * 4;
+      s_live[pos][1] = (wt * Cin) * 4;
+      s_live[pos][2] = (int)(1u << t);
+      s_live[pos][3] = 0;
+    }
     __syncthreads();
-    int buf = 0;
-    const int lrow = lane & 31, lh = lane >> 5;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool has_next = kt + 1 < kt_end;
-      if (has_next) load_tile(kt + 1);
-      const float* Ab = &As[buf][(wm * WM + lrow) * LDK + lh * 4];
-      const float* Bb = &Bs[buf][(wn * WN + lrow) * LDK + lh * 4];
+    const int cpt = Cin / BK;
+    const int nlive = __popc(tapmask);
+    const int total = nlive * cpt;
+    const int per = (total + d.splitk - 1) / d.splitk;
+    const int qb = blockIdx.z * per;
+    const int qe = min(total, qb + per);
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, d.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;  // >= num_records: the load returns 0
+    unsigned aoffB[AP], woffB[BP];
 #pragma unroll
-      for (int kg = 0; kg < BK / 8; ++kg) {
-        f32x4 a[TM], b[TN];
+    for (int i = 0; i < AP; ++i) aoffB[i] = (unsigned)(aoff[i] + c4 * 4) * 4u;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + kg * 8);
+    for (int j = 0; j < BP; ++j) {
+      const int n = n0 + r0 + 32 * j;
+      woffB[j] = n < d.Cout ? (unsigned)(((long long)n * d.ldw + c4 * 4) * 4) : OOB;
+    }
+    struct Ctx { int doff, woff; unsigned bit; };
+    auto tile_ctx = [&](int li, int ch, bool live) -> Ctx {
+      const int lc = li < nlive ? li : (nlive > 0 ? nlive - 1 : 0);
+      const int4 ti = *reinterpret_cast<const int4*>(&s_live[lc][0]);
+      Ctx cx;
+      cx.doff = ti.x + ch * (BK * 4);
+      cx.woff = live ? ti.y + ch * (BK * 4) : (int)OOB;
+      cx.bit = live ? (unsigned)ti.z : 0u;
+      return cx;
+    };
+    auto load_a = [&](const Ctx& cx, int i) {
+      const unsigned off = (amask[i] & cx.bit) ? aoffB[i] + (unsigned)cx.doff : OOB;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0));
+    };
+    auto load_b = [&](const Ctx& cx, int j) {
+      // an invalid row / dead tile keeps the offset out of range (weights are < 2 GiB, checked on the host)
+      const unsigned off = (woffB[j] | (unsigned)cx.woff) >= OOB ? OOB : woffB[j] + (unsigned)cx.woff;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0));
+    };
+    if (qb < qe) {
+      int q = qb;
+      int li = q / cpt, ch = q - li * cpt;
+      {
+        const Ctx c0 = tile_ctx(li, ch, true);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + kg * 8);
+        for (int i = 0; i < AP; ++i) load_a(c0, i);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < BP; ++j) load_b(c0, j);
       }
-      if (has_next) store_tile(buf ^ 1);
+      store_tile(0);
+      if (++ch == cpt) { ch = 0; ++li; }
+      Ctx cxn = tile_ctx(li, ch, q + 1 < qe);
       __syncthreads();
-      buf ^= 1;
+      int buf = 0;
+      while (q < qe) {
+        const float* Ac = Ab + buf * (BM * LDK);
+        const float* Bc = Bb + buf * (BN * LDK);
+        float* Aw = &As[buf ^ 1][r0 * LDK + c4 * 4];
+        float* Bw = &Bs[buf ^ 1][r0 * LDK + c4 * 4];
+        Ctx cxn2 = cxn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDK);
+        // One MFMA per slot; behind each, at most one memory instruction:
+        //   first quarter  : the NL global gathers of the next tile
+        //   per k-group    : the TM+TN fragment reads of the next k-group
+        //   last quarter   : the NL LDS writes of the next tile (its gathers are >= NMF/2 MFMAs old)
+#pragma unroll
+        for (int s = 0; s < NMF; ++s) {
+          const int kg = s / (4 * TM * TN), e = (s / (TM * TN)) & 3, i = (s / TN) % TM, j = s % TN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kg & 1][i][e], fb[kg & 1][j][e], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          {  // gathers: slot s issues gather x when x == s * NL / (NMF/4) over the first quarter
+            constexpr int Q = NMF / 4;
+            if (s < Q) {
+#pragma unroll
+              for (int x = 0; x < NL; ++x) {
+                if ((x * Q) / NL != s) continue;
+                if (x < AP) load_a(cxn, x); else load_b(cxn, x - AP);
+              }
+            }
+          }
+          {  // fragment reads of k-group kg+1, one per slot, starting at the 2nd slot of the group
+            const int sg = s - kg * 4 * TM * TN - 1;
+            if (kg < 3 && sg >= 0 && sg < TM + TN) {
+              if (sg < TM)
+                fa[(kg + 1) & 1][sg] = *reinterpret_cast<const f32x4*>(Ac + sg * 32 * LDK + (kg + 1) * 8);
+              else
+                fb[(kg + 1) & 1][sg - TM] = *reinterpret_cast<const f32x4*>(Bc + (sg - TM) * 32 * LDK + (kg + 1) * 8);
+            }
+          }
+          if (s == NMF / 2) {  // constants of the tile after next (LDS broadcast read, consumed next iteration)
+            if (++ch == cpt) { ch = 0; ++li; }
+            cxn2 = tile_ctx(li, ch, q + 2 < qe);
+          }
+          {  // LDS writes over the last quarter
+            constexpr int Q = NMF / 4;
+            const int sw = s - 3 * Q;
+            if (sw >= 0) {
+#pragma unroll
+              for (int x = 0; x < NL; ++x) {
+                if ((x * Q) / NL != sw) continue;
+                if (x < AP) *reinterpret_cast<f32x4*>(Aw + 32 * x * LDK) = ra[x];
+                else *reinterpret_cast<f32x4*>(Bw + 32 * (x - AP) * LDK) = rb[x - AP];
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        cxn = cxn2;
+        __syncthreads();
+        buf ^= 1;
+        ++q;
+      }
+    }
+  } else {
+    // ================= generic path (first layers: channel stride not a multiple of 32) =================
+    const int Ktot = ntaps * Cin;
+    const int nkt = (Ktot + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * d.kt_per_split;
+    const int kt_end = min(nkt, kt_begin + d.kt_per_split);
+    const float* wptr[BP];
+    bool bvalid[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      const int n = n0 + r0 + 32 * j;
+      bvalid[j] = n < d.Cout;
+      wptr[j] = d.w + (long long)(bvalid[j] ? n : 0) * d.ldw;
+    }
+    auto tile_live = [&](int kt) -> bool {
+      const int tlo = (kt * BK) / Cin;
+      int thi = (kt * BK + BK - 1) / Cin;
+      if (thi > ntaps - 1) thi = ntaps - 1;
+      const unsigned span = (thi - tlo + 1) >= 32 ? 0xffffffffu : ((1u << (thi - tlo + 1)) - 1u);
+      return ((tapmask >> tlo) & span) != 0u;
+    };
+    auto next_live = [&](int kt) -> int {
+      while (kt < kt_end && !tile_live(kt)) ++kt;
+      return kt;
+    };
+    auto load_tile = [&](int kt, bool live) {
+      const int kflat = kt * BK + c4 * 4;
+      if (MODE == 1) {
+        const bool kvalid = live && kflat < Ktot;
+        const int tap = kvalid ? kflat / Cin : 0;
+        const int c = kflat - tap * Cin;
+        const int tv = s_tap[tap];
+        const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
+        const int doff = (dh * Win + dw) * Cin + c;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          const bool ok = kvalid && ((amask[i] >> tap) & 1u);
+          const float* pa = ok ? d.in + aoff[i] + doff : g_zero;
+          ra[i] = *reinterpret_cast<const f32x4*>(pa);
+        }
+        const int woff = wt * Cin + c;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+          const float* pb = (kvalid && bvalid[j]) ? wptr[j] + woff : g_zero;
+          rb[j] = *reinterpret_cast<const f32x4*>(pb);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kf = kflat + e;
+          const bool kvalid = live && kf < Ktot;
+          const int tap = kvalid ? kf / Cin : 0;
+          const int c = kf - tap * Cin;
+          const int tv = s_tap[tap];
+          const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
+          const int doff = (dh * Win + dw) * Cin + c;
+#pragma unroll
+          for (int i = 0; i < AP; ++i) {
+            const bool ok = kvalid && ((amask[i] >> tap) & 1u);
+            const float* pa = ok ? d.in + aoff[i] + doff : g_zero;
+            ra[i][e] = *pa;
+          }
+          const int woff = wt * Cin + c;
+#pragma unroll
+          for (int j = 0; j < BP; ++j) {
+            const float* pb = (kvalid && bvalid[j]) ? wptr[j] + woff : g_zero;
+            rb[j][e] = *pb;
+          }
+        }
+      }
+    };
+    int kt = next_live(kt_begin);
+    if (kt < kt_end) {
+      load_tile(kt, true);
+      store_tile(0);
+      __syncthreads();
+      int buf = 0;
+      while (kt < kt_end) {
+        const int nk = next_live(kt + 1);
+        load_tile(nk, nk < kt_end);
+        const float* Ac = Ab + buf * (BM * LDK);
+        const float* Bc = Bb + buf * (BN * LDK);
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDK + kg * 8);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDK + kg * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][i][e], fb[0][j][e], acc[i][j], 0, 0, 0);
+        }
+        store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        kt = nk;
+      }
     }
   }
 
-  // epilogue: acc(row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31)
+  // epilogue: acc(row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31).  Row offsets are fetched from LDS in one
+  // batch, the optional mask / act' operands in one batch of global loads (no branch, no wait per element).
   const AliEpilogue& ep = d.ep;
   const bool partial = d.splitk > 1;
   float* outp = partial ? d.ws + (long long)blockIdx.z * d.out_elems : d.out;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 32 + (lane & 31);
-    if (n >= d.Cout) continue;
-    const float bias = (!partial && ep.bias) ? ep.bias[n] : 0.f;
+  auto run_epilogue = [&](auto has_mask_t, auto has_dact_t) {
+    constexpr bool HAS_MASK = decltype(has_mask_t)::value, HAS_DACT = decltype(has_dact_t)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const long long off = s_rowoff[row];
-        if (off < 0) continue;
-        float v = acc[i][j][r];
-        if (!partial) {
-          v = apply_act(v + bias, ep.act, ep.slope);
-          if (ep.mask) v *= ep.mask[(long long)s_rowimg[row] * ep.mask_ld + n];
-          if (ep.dact_y) v *= act_grad_from_output(ep.dact_y[off + n], ep.dact, ep.dslope);
+      for (int h = 0; h < 2; ++h) {  // 8 rows at a time keeps the register footprint small
+        int roff[8], rimg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = h * 8 + q;
+          const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          roff[q] = s_rowoff[row];
+          if (HAS_MASK) rimg[q] = s_rowimg[row];
         }
-        outp[off + n] = v;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WN + j * 32 + (lane & 31);
+          const bool nok = n < d.Cout;
+          const int nc = nok ? n : 0;
+          const float bias = (!partial && ep.bias) ? ep.bias[nc] : 0.f;
+          float mk[8], dy[8];
+          if (HAS_MASK) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mk[q] = ep.mask[(long long)rimg[q] * ep.mask_ld + nc];
+          }
+          if (HAS_DACT) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dy[q] = ep.dact_y[(roff[q] < 0 ? 0 : roff[q]) + nc];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float v = acc[i][j][h * 8 + q];
+            if (!partial) {
+              v = apply_act(v + bias, ep.act, ep.slope);
+              if (HAS_MASK) v *= mk[q];
+              if (HAS_DACT) v *= act_grad_from_output(dy[q], ep.dact, ep.dslope);
+            }
+            if (nok && roff[q] >= 0) outp[roff[q] + n] = v;
+          }
+        }
       }
     }
-  }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  const bool hm = !partial && ep.mask != nullptr, hd = !partial && ep.dact_y != nullptr;
+  if (hm && hd) run_epilogue(T_{}, T_{});
+  else if (hm) run_epilogue(T_{}, F_{});
+  else if (hd) run_epilogue(F_{}, T_{});
+  else run_epilogue(F_{}, F_{});
 }
 
 // out = epilogue(sum_s ws[s]) over the flat NHWC output
@@ -275,30 +508,57 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long l
 
 struct TileCfg { int bm, bn; };
 
+// fp32 MFMA cannot overlap with VALU work of the same SIMD, and a lone wave per SIMD cannot hide its barrier / memory
+// waits: prefer the largest tile that still gives every CU two resident blocks (>= 512 blocks), measured best on the
+// MorphoMNIST layer shapes at bs=512 (scratch/mb3.py).
 static TileCfg pick_tile(long long M, int N) {
-  TileCfg c;
-  c.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
-  c.bm = 128;
-  if (c.bn == 128 && M * (long long)((N + 127) / 128) < 128LL * 256) c.bm = 64;  // too few tiles: halve M tile
-  if (c.bn == 64 && M < 128LL * 256) c.bm = 64;
-  return c;
+  TileCfg best = {64, 64};
+  if (N <= 32) { best.bm = 128; best.bn = 32; return best; }
+  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (long long)((N + bn - 1) / bn); };
+  // measured (scratch/mb3.py): 64x64 (4 resident blocks per CU) wins or ties up to a few thousand blocks;
+  // larger tiles only pay through lower L2/HBM traffic once the grid is many waves deep
+  if (blocks(64, 64) <= 16 * kNumCU || N <= 64) return best;
+  if (blocks(64, 128) <= 16 * kNumCU) { best.bm = 64; best.bn = 128; return best; }
+  best.bm = 128; best.bn = 128;
+  return best;
 }
 
 static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec) {
   long long Mtot = 0;
-  for (int i = 0; i < d.nphase; ++i) Mtot += d.ph[i].M;
-  TileCfg tc = pick_tile(Mtot, d.Cout);
-  if (!vec) { tc.bm = 128; if (tc.bn == 128) tc.bn = 64; }
-  int tiles = 0, max_nkt = 0;
+  int max_taps = 0;
   for (int i = 0; i < d.nphase; ++i) {
+    Mtot += d.ph[i].M;
+    if (d.ph[i].nr * d.ph[i].ns > max_taps) max_taps = d.ph[i].nr * d.ph[i].ns;
+    if (d.ph[i].M >= (1 << 24)) { set_error("gconv: more than 2^24 rows in one phase"); return ALI_ERR_BAD_ARG; }
+  }
+  const int max_nkt = (max_taps * d.Cin + BK - 1) / BK;
+  const bool uni = vec && (d.Cin % BK) == 0;
+  TileCfg tc = pick_tile(Mtot, d.Cout);
+  if (!vec && tc.bn == 128) tc.bn = 64;
+  {
+    const char* bm = getenv("ALI_BM");
+    const char* bn = getenv("ALI_BN");
+    if (bm && bn && atoi(bm) > 0) { tc.bm = atoi(bm); tc.bn = atoi(bn); }
+  }
+  int tiles = 0;
+  for (int i = 0; i < d.nphase; ++i) {
+    // small maps with a large batch: order rows (pixel, image) so that every M-tile sees one pixel position
+    // and the taps falling outside the input (padding, 1x1 -> 3x3 transposed convs) are skipped tile-wide
+    d.ph[i].pixmajor = (d.ph[i].Hq * d.ph[i].Wq <= 64 && d.B >= 32) ? 1 : 0;
     d.ph[i].tile0 = tiles;
     tiles += (d.ph[i].M + tc.bm - 1) / tc.bm;
-    int nkt = (d.ph[i].ntaps * d.Cin + BK - 1) / BK;
-    if (nkt > max_nkt) max_nkt = nkt;
   }
   const int ntile_n = (d.Cout + tc.bn - 1) / tc.bn;
   d.out_elems = (long long)d.B * d.Hout * d.Wout * d.ldo;
-  // split-K when the grid cannot fill 256 CUs x 2 resident blocks
+  const long long in_elems = (long long)d.B * d.Hin * d.Win * d.Cin;
+  const long long w_elems = (long long)d.Cout * d.ldw;
+  if (d.out_elems >= (1LL << 31) || in_elems >= (1LL << 30) || w_elems >= (1LL << 29)) {
+    set_error("gconv: tensor too large for 32-bit byte offsets");
+    return ALI_ERR_BAD_ARG;
+  }
+  d.in_bytes = (unsigned)(in_elems * 4);
+  d.w_bytes = (unsigned)(w_elems * 4);
+  // split-K when the grid cannot give every CU two blocks
   int S = 1;
   const long long blocks = (long long)tiles * ntile_n;
   if (blocks < 2 * kNumCU && max_nkt >= 8) {
@@ -308,16 +568,21 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     while (S > 1 && (size_t)S * d.out_elems * sizeof(float) > ws_bytes) --S;
     if (S < 1) S = 1;
   }
+  {
+    const char* fs = getenv("ALI_SPLITK");
+    if (fs && atoi(fs) > 0) S = atoi(fs);
+  }
   d.splitk = S;
   d.kt_per_split = (max_nkt + S - 1) / S;
   if (d.kt_per_split < 1) d.kt_per_split = 1;
   d.ws = reinterpret_cast<float*>(ws);
   dim3 grid(tiles, ntile_n, S), block(256);
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
-#define LAUNCH(BM_, BN_, WMM, WNN)                                                            \
-  do {                                                                                          \
-    if (vec) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, true>), grid, block, 0, stream, d); \
-    else hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, false>), grid, block, 0, stream, d);    \
+#define LAUNCH(BM_, BN_, WMM, WNN)                                                                    \
+  do {                                                                                                  \
+    if (uni) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2>), grid, block, 0, stream, d);      \
+    else if (vec) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 1>), grid, block, 0, stream, d); \
+    else hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 0>), grid, block, 0, stream, d);          \
   } while (0)
   if (tc.bm == 128 && tc.bn == 128) LAUNCH(128, 128, 2, 2);
   else if (tc.bm == 128 && tc.bn == 64) LAUNCH(128, 64, 2, 2);
@@ -341,8 +606,8 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
 static bool geom_ok(const AliConvGeom* g) {
   if (!g) return false;
   if (g->B <= 0 || g->H <= 0 || g->W <= 0 || g->C <= 0 || g->P <= 0 || g->Q <= 0 || g->K <= 0) return false;
-  if (g->R <= 0 || g->S <= 0 || g->R * g->S > kMaxTaps || g->stride <= 0 || g->pad < 0) return false;
-  if (g->pad > 100 || g->R > 100 || g->S > 100) return false;  // taps are stored as signed bytes
+  if (g->R <= 0 || g->S <= 0 || g->R > kMaxGrid || g->S > kMaxGrid || g->stride <= 0 || g->pad < 0) return false;
+  if (g->pad > 100) return false;  // taps are stored as signed bytes
   return true;
 }
 
@@ -375,18 +640,14 @@ extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w
   d.B = g->B; d.Hin = g->H; d.Win = g->W; d.Cin = g->C;
   d.Hout = g->P; d.Wout = g->Q; d.Cout = g->K; d.ldo = g->K;
   d.ldw = g->R * g->S * g->C;
+  d.S = g->S;
   d.nphase = 1;
   Phase& P = d.ph[0];
   P.Hq = g->P; P.Wq = g->Q; P.oh0 = 0; P.ow0 = 0; P.ostep = 1; P.mult = g->stride;
   P.M = g->B * g->P * g->Q;
-  P.ntaps = 0;
-  for (int r = 0; r < g->R; ++r)
-    for (int s = 0; s < g->S; ++s) {
-      P.dh[P.ntaps] = (signed char)(r - g->pad);
-      P.dw[P.ntaps] = (signed char)(s - g->pad);
-      P.wt[P.ntaps] = (unsigned char)(r * g->S + s);
-      ++P.ntaps;
-    }
+  P.nr = g->R; P.ns = g->S;
+  for (int r = 0; r < g->R; ++r) { P.dh[r] = (signed char)(r - g->pad); P.wr[r] = (unsigned char)r; }
+  for (int s = 0; s < g->S; ++s) { P.dw[s] = (signed char)(s - g->pad); P.ws[s] = (unsigned char)s; }
   return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->C % 4) == 0);
 }
 
@@ -400,6 +661,7 @@ extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const fl
   d.B = g->B; d.Hin = g->P; d.Win = g->Q; d.Cin = g->K;
   d.Hout = g->H; d.Wout = g->W; d.Cout = g->C; d.ldo = g->C;
   d.ldw = g->R * g->S * g->K;
+  d.S = g->S;
   const int st = g->stride;
   if (st > 2) { set_error("ali_conv_bwd_data: stride %d unsupported", st); return ALI_ERR_BAD_ARG; }
   d.nphase = 0;
@@ -410,19 +672,20 @@ extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const fl
       Phase& P = d.ph[d.nphase++];
       P.Hq = Hq; P.Wq = Wq; P.oh0 = ph; P.ow0 = pw; P.ostep = st; P.mult = 1;
       P.M = g->B * Hq * Wq;
-      P.ntaps = 0;
+      P.nr = P.ns = 0;
       for (int r = 0; r < g->R; ++r) {
         const int nh = ph + g->pad - r;
         if (((nh % st) + st) % st) continue;
-        for (int s = 0; s < g->S; ++s) {
-          const int nw = pw + g->pad - s;
-          if (((nw % st) + st) % st) continue;
-          // exact division (nh, nw are multiples of st)
-          P.dh[P.ntaps] = (signed char)(nh / st);
-          P.dw[P.ntaps] = (signed char)(nw / st);
-          P.wt[P.ntaps] = (unsigned char)(r * g->S + s);
-          ++P.ntaps;
-        }
+        P.dh[P.nr] = (signed char)(nh / st);  // exact: nh is a multiple of st
+        P.wr[P.nr] = (unsigned char)r;
+        ++P.nr;
+      }
+      for (int s = 0; s < g->S; ++s) {
+        const int nw = pw + g->pad - s;
+        if (((nw % st) + st) % st) continue;
+        P.dw[P.ns] = (signed char)(nw / st);
+        P.ws[P.ns] = (unsigned char)s;
+        ++P.ns;
       }
     }
   return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->K % 4) == 0);

@@ -101,7 +101,7 @@ class Generator(nn.Module):
         feats = [z.reshape(B, LATENT_DIM).float(), digit.reshape(B, 256)] + [c[k].reshape(B, 1).float()
                                                                              for k in _cont_keys(c)]
         n_log = sum(f.shape[1] for f in feats)
-        pad = (-n_log) % 4
+        pad = (-n_log) % 32          # channel stride % 32 == 0 -> uniform-tap fast path of the GEMM kernel
         if pad:
             feats.append(torch.zeros(B, pad, device=z.device))
         x0 = torch.cat(feats, dim=1).reshape(B, 1, 1, n_log + pad)

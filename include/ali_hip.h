@@ -86,6 +86,25 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                         int32_t Cg_log, int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
 
+/* ---- direct kernels for the one-channel ends of the stacks (VALU + LDS, HBM bound) ----------
+ * Stride-1 correlations between a K-channel NHWC map `big` [B,P,Q,K] and a 1-channel map `small`
+ * [B,H,W] (H = P+R-1-2*pad), used for ConvTranspose2d(64->1,k4)+Tanh (mnist.py:72-73) and for the single
+ * consumed input plane / per-input-channel weight gradient of a first Conv2d (mnist.py:108):
+ *   fwd   : out[b,h,w]    = act(bias + sum_{r,s,k} big[b,h+pad-r,w+pad-s,k] * w_tk[r*S+s][k])
+ *   dgrad : gbig[b,p,q,k] = act'(y[b,p,q,k]) * sum_{r,s} small[b,p+r-pad,q+s-pad] * w_tk[r*S+s][k]
+ *   wgrad : dw[c*s_c + k*s_k + (r*S+s)*s_tap] = sum_{b,p,q} big[b,p,q,k] * small[b,p+r-pad,q+s-pad][c]
+ *           for the first nc (<= 8) channels c of `small` (element stride sstride between pixels)
+ * `sstride` / `ostride`: element stride of the 1-channel map when it is one plane of an NHWC tensor. */
+int ali_tconv1_fwd(const float* big, const float* w_tk, const float* bias, float* out, int32_t B, int32_t P,
+                   int32_t Q, int32_t K, int32_t R, int32_t S, int32_t pad, int32_t ostride, int32_t act,
+                   float slope, ali_stream_t stream);
+int ali_tconv1_dgrad(const float* small, int32_t sstride, const float* w_tk, const float* dact_y, int32_t dact,
+                     float dslope, float* gbig, int32_t B, int32_t P, int32_t Q, int32_t K, int32_t R, int32_t S,
+                     int32_t pad, ali_stream_t stream);
+int ali_tconv1_wgrad(const float* big, const float* small, int32_t sstride, int32_t nc, float* dw, int64_t s_k,
+                     int64_t s_tap, int64_t s_c, int32_t B, int32_t P, int32_t Q, int32_t K, int32_t R, int32_t S,
+                     int32_t pad, void* ws, size_t ws_bytes, ali_stream_t stream);
+
 /* dst[(n*T+t)*Cpad + c] = c < C ? src[n*s_n + t*s_tap + c*s_c] : 0.
  * Re-lays reference-layout parameters ([Cout,Cin,kh,kw] Conv2d, [Cin,Cout,kh,kw]
  * ConvTranspose2d, [out,in] Linear) into the kernel layouts.   */

@@ -1,0 +1,25 @@
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "imagecfgen-pytorch_amd")]
+import torch
+from ali_hip import ops
+def bench(B,H,C,K,R,st,pad, iters=30):
+    P = (H + 2*pad - R)//st + 1
+    x = torch.randn(B,H,H,C, device="cuda"); w = torch.randn(K,R*R,C, device="cuda")*0.05
+    y = torch.empty(B,P,P,K, device="cuda"); b = torch.randn(K, device="cuda")
+    g = ops.geom(B,H,H,C,P,P,K,R,R,st,pad); ep = ops.epilogue(bias=b, act=ops.ACT_LEAKY, slope=0.2)
+    for _ in range(3): ops.conv_fwd(g,x,w,y,ep)
+    torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): ops.conv_fwd(g,x,w,y,ep)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1)*1e3/iters
+    fl = 2.0*B*P*P*K*C*R*R
+    return us, fl/us/1e6
+shapes = [(512,11,64,128,4,1,0),(512,8,128,256,4,2,0),(512,24,32,64,4,2,0),(512,14,64,128,4,2,1),(512,1,1024,1024,1,1,0),(512,3,256,512,3,1,0), (2048,11,64,128,4,1,0)]
+for dbg, bm, bn in (("0","128","128"),("16","128","128"),("0","64","128"),("16","64","128"),("0","128","64"),("16","128","64"),("0","64","64"),("16","64","64")):
+    os.environ["ALI_BM"]=bm; os.environ["ALI_BN"]=bn
+    os.environ["ALI_DBG"]=dbg
+    for sk in ("1",):
+        os.environ["ALI_SPLITK"]=sk
+        print("dbg",dbg,bm,bn,"splitk",sk or "auto", " ".join(f"{bench(*s)[0]:7.1f}us/{bench(*s)[1]:5.1f}TF" for s in shapes), flush=True)

@@ -250,3 +250,46 @@ def test_assemble_planes_matches_torch_modules():
     out2 = ops.assemble_planes(X2.cuda(), idx.to(torch.int32).reshape(B, 1).cuda(), [emb.weight.detach().cuda()],
                                None, B, 128, 128, 4)
     close(out2[..., 1], seq2(idx)[:, 0], rtol=1e-6, what="planes x8")
+
+
+@pytest.mark.parametrize("B,K,P,R,pad", [(5, 64, 25, 4, 0), (3, 32, 24, 5, 0), (2, 64, 9, 3, 1), (2, 128, 6, 3, 1)])
+def test_direct_one_channel_kernels(B, K, P, R, pad):
+    """ali_tconv1_{fwd,dgrad,wgrad}: ConvTranspose2d(K -> 1, stride 1) forward / input gradient / weight gradient."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + P)
+    x = torch.randn(B, K, P, P, generator=g)
+    w = torch.randn(K, 1, R, R, generator=g) * 0.2
+    b = torch.randn(1, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yprev = F.leaky_relu(xr, 0.2)
+    yr = torch.tanh(F.conv_transpose2d(yprev, wr, br, stride=1, padding=pad))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    H = yr.shape[2]
+    T = R * R
+    xin = nhwc(yprev.detach()).cuda()
+    w_tk = torch.empty(1, T, K, device="cuda")
+    ops.pack_weights(w.cuda().contiguous(), w_tk, 1, T, K, K, T, 1, T)
+    y = torch.empty(B, H, H, 1, device="cuda")
+    ops.tconv1_fwd(xin, w_tk, b.cuda(), y, B, P, P, K, R, R, pad, 1, ops.ACT_TANH, 0.0)
+    close(nchw(y), yr, what="tconv1 fwd")
+    gpre = ops.act_bwd(nhwc(gy).cuda(), y, ops.ACT_TANH, 0.0)
+    gx = torch.empty(B, P, P, K, device="cuda")
+    ops.tconv1_dgrad(gpre, 1, w_tk, xin, ops.ACT_LEAKY, 0.2, gx, B, P, P, K, R, R, pad)
+    close(nchw(gx), xr.grad, what="tconv1 dgrad (fused leaky')")
+    dw = torch.empty(K, 1, R, R, device="cuda")
+    ops.tconv1_wgrad(xin, gpre, 1, 1, dw, T, 1, 0, B, P, P, K, R, R, pad)
+    close(dw, wr.grad, what="tconv1 wgrad")
+    # strided planes: output into / small operand from one channel of an NHWC tensor
+    y4 = torch.zeros(B, H, H, 4, device="cuda")
+    ops.tconv1_fwd(xin, w_tk, b.cuda(), y4[..., 2], B, P, P, K, R, R, pad, 4, ops.ACT_TANH, 0.0)
+    close(y4[..., 2], y[..., 0], rtol=1e-6, what="strided out")
+    # several small channels at once (first-layer weight gradient dW[k][c][tap]): channel 1 carries gpre
+    g4 = torch.randn(B, H, H, 4, generator=g).cuda()
+    g4[..., 1] = gpre[..., 0]
+    dw2 = torch.zeros(K, 3, R, R, device="cuda")
+    ops.tconv1_wgrad(xin, g4, 4, 3, dw2, 3 * T, 1, T, B, P, P, K, R, R, pad)
+    close(dw2[:, 1], dw[:, 0], rtol=1e-6, what="multi-channel small")
+    ref0 = torch.empty(K, 1, R, R, device="cuda")
+    ops.tconv1_wgrad(xin, g4[..., 0].contiguous(), 1, 1, ref0, T, 1, 0, B, P, P, K, R, R, pad)
+    close(dw2[:, 0], ref0[:, 0], rtol=1e-6, what="multi-channel small, plane 0")
