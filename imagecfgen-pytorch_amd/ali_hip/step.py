@@ -95,11 +95,36 @@ class MnistFamily:
         return idx, cont, onehots
 
 
+class SpectFamily:
+    """Input assembly of the spectrogram models (audio_mnist.py:203-210,250-256,309-318 and the whale / ESRF copies):
+    categorical attributes -> embedding planes (E, D) / one-hot @ table (G), optional continuous plane (ESRF)."""
+    name = "spect"
+
+    def __init__(self, E, G, D):
+        self.hw = tuple(E.image_hw)
+        self.cat_keys = tuple(E.cat_keys)
+        self.cont_key = E.cont_key
+        self.e_tables = [E.plane_module(k)[0].weight for k in self.cat_keys]
+        self.d_tables = [D.plane_module(k)[0].weight for k in self.cat_keys]
+        self.g_tables = [G.table(k).weight for k in self.cat_keys]
+
+    def conditioning(self, c):
+        B = c[self.cat_keys[0]].shape[0]
+        idx = torch.stack([c[k].argmax(dim=1) for k in self.cat_keys], dim=1).to(torch.int32).contiguous()
+        cont = c[self.cont_key].reshape(B, 1).float().contiguous() if self.cont_key is not None else None
+        onehots = [c[k].float() for k in self.cat_keys]
+        return idx, cont, onehots
+
+
+def family_of(E, G, D):
+    return SpectFamily(E, G, D) if hasattr(E, "cat_keys") else MnistFamily(E, G, D)
+
+
 class AliStepper:
     def __init__(self, E, G, D, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, family=None, process_group=None,
                  capture=False):
         self.E, self.G, self.D = E, G, D
-        self.family = family or MnistFamily(E, G, D)
+        self.family = family or family_of(E, G, D)
         self.pE, self.pG = get_plan(E.layers), get_plan(G.layers)
         self.pDx, self.pDz, self.pDxz = get_plan(D.dx), get_plan(D.dz), get_plan(D.dxz)
         self.opt_eg = FlatGroup(list(E.parameters()) + list(G.parameters()), lr, betas, eps)

@@ -80,3 +80,28 @@ def test_batchify_and_helpers():
     img = torch.zeros(2, 1, 8, 8)
     assert tu.binarized_attribute_channel(img, torch.tensor([[0., 1.], [1., 0.]])).sum().item() == 128
     assert tu.attributes_image(img, torch.ones(2, 3)).shape == (2, 2, 8, 8)
+
+
+@pytest.mark.parametrize("family,modname,d,B", [("audio", "audio_mnist", 8, 2), ("whale", "whalecalls", 8, 1),
+                                                  ("esrf", "esrf_acoustic", 4, 1)])
+def test_product_spect_modules_match_oracle_on_cpu(family, modname, d, B):
+    """ctor / init RNG order, state_dict keys and CPU forward of the spectrogram families == oracle (== reference)."""
+    import importlib
+    pm = importlib.import_module(f"image_scms.{modname}")
+    torch.manual_seed(5)
+    Eo, Go, Do = orc.build_models(family, d)
+    torch.manual_seed(5)
+    E, G, D = pm.Encoder(d), pm.Generator(d), pm.Discriminator(d)
+    for m in (E, G, D):
+        m.apply(pm.init_weights)
+    assert orc.weights_digest(E, G, D) == orc.weights_digest(Eo, Go, Do)
+    for mo, mp in ((Eo, E), (Go, G), (Do, D)):
+        assert list(mp.state_dict()) == list(mo.state_dict())
+    images, a, z = orc.synth_spect_batch(family, B, seed=3)
+    a["path"] = torch.zeros(B, 1)                      # callers pass whole batch dicts: extra keys are ignored
+    for m in (E, G, D, Eo, Go, Do):
+        m.eval()
+    assert torch.equal(E(images, a), Eo(images, a))
+    assert torch.equal(G(z, a), Go(z, a))
+    assert torch.equal(D(images, z, a), Do(images, z, a))
+    assert torch.equal(G(z.reshape(B, 512), a), Go(z, a))       # z may be [B,512] (reference audio_mnist.py:251)
