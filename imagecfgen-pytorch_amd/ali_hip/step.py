@@ -135,6 +135,8 @@ class AliStepper:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.capture = capture
+        self.segmented = False     # tests: force the data-parallel (segmented) replay on a single rank
+        self._capture_snapshot = None
         self._graph = None
 
         self.bn_buffers = [b for n_, b in D.named_buffers() if "running" in n_]
@@ -197,12 +199,6 @@ class AliStepper:
                                    need_params, dst)
         return gx0, gz
 
-    def _reduce_and_step(self, group: FlatGroup):
-        """DP: one RCCL all-reduce(sum) of the flat gradient; the 1/world average is folded into Adam."""
-        if self.world > 1:
-            dp.allreduce_sum_(group.grad, self.pg)
-        group.adam(1.0 / self.world)
-
     # ------------------------------------------------------------------ the iteration, phase by phase
     def _begin(self, images, c, z):
         B = images.shape[0]
@@ -212,8 +208,8 @@ class AliStepper:
         return {"images": images, "B": B, "idx": idx, "cont": cont, "onehots": onehots,
                 "zin": z.reshape(B, -1).float().contiguous(), "out": {}}
 
-    def _phase_eg(self, cx):
-        """E+G update (reference mnist.py:224-230)."""
+    def _eg_grads(self, cx):
+        """E+G gradients (reference mnist.py:224-229)."""
         fam, images, idx, cont, onehots, zin, B = (self.family, cx["images"], cx["idx"], cx["cont"], cx["onehots"],
                                                    cx["zin"], cx["B"])
         x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
@@ -241,12 +237,36 @@ class AliStepper:
         for oh, t in zip(onehots, fam.g_tables):
             dst[id(t)].copy_(oh.t().matmul(g_gin[:, off:off + 256]))
             off += 256
-        self._reduce_and_step(self.opt_eg)
+
+    def _apply_eg(self):
+        self.opt_eg.adam(1.0 / self.world)
         self.pE.cache.refresh()
         self.pG.cache.refresh()
 
+    def _apply_d(self):
+        self.opt_d.adam(1.0 / self.world)
+        self._refresh_d()
+
+    def _phase_eg(self, cx):
+        self._eg_grads(cx)
+        if self.world > 1:
+            dp.allreduce_sum_(self.opt_eg.grad, self.pg)
+        self._apply_eg()
+
     def _phase_d_real(self, cx):
-        """D update on (x, E'(x)) (reference mnist.py:232-236); E' forward only."""
+        self._d_real_grads(cx)
+        if self.world > 1:
+            dp.allreduce_sum_(self.opt_d.grad, self.pg)
+        self._apply_d()
+
+    def _phase_d_fake(self, cx):
+        self._d_fake_grads(cx)
+        if self.world > 1:
+            dp.allreduce_sum_(self.opt_d.grad, self.pg)
+        self._apply_d()
+
+    def _d_real_grads(self, cx):
+        """D gradients on (x, E'(x)) (reference mnist.py:232-235); E' forward only."""
         fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
         x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
         ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
@@ -256,12 +276,10 @@ class AliStepper:
         cx["out"]["loss_d_real"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0d, idx, fam.d_tables, self.opt_d.grad_views)
-        self._reduce_and_step(self.opt_d)
-        self._refresh_d()
         cx["ex"], cx["n_log"] = ex, n_log
 
-    def _phase_d_fake(self, cx):
-        """D update on (G'(z), z) (reference mnist.py:237-241); G' forward only."""
+    def _d_fake_grads(self, cx):
+        """D gradients on (G'(z), z) (reference mnist.py:237-240); G' forward only."""
         fam, idx, cont, zin = self.family, cx["idx"], cx["cont"], cx["zin"]
         gin, g_log = self._g_input(zin, cx["onehots"], cont)
         gz, _ = chain_forward(self.pG, gin, True, g_log, False)
@@ -271,11 +289,9 @@ class AliStepper:
         cx["out"]["loss_d_fake"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0f, idx, fam.d_tables, self.opt_d.grad_views)
-        self._reduce_and_step(self.opt_d)
-        self._refresh_d()
         cx["gz"] = gz
 
-    def _phase_scores(self, cx):
+    def _phase_scores(self, cx, average_bn=True):
         """sigma(D(G(z),z)).mean(), sigma(D(x,E(x))).mean() (reference mnist.py:243-248): forward only, train mode,
         re-using G'(z) and E'(x) of the D phases (the reference recomputes identical values)."""
         fam, images, idx, cont, zin = self.family, cx["images"], cx["idx"], cx["cont"], cx["zin"]
@@ -285,9 +301,22 @@ class AliStepper:
         de, _ = self._d_forward(x0d, cx["n_log"], cx["ex"], False)
         cx["out"]["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
         cx["out"]["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
-        if self.world > 1:
+        if self.world > 1 and average_bn:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
             dp.average_buffers_(self.bn_buffers, self.pg)
+
+    def _segments(self, do_eg):
+        """The iteration cut at its data-parallel exchanges: every segment is pure device work (capturable in a HIP
+        graph); between segments one RCCL all-reduce of a flat gradient buffer runs eagerly on the same stream."""
+        segs = []
+        if do_eg:
+            segs.append((lambda cx: self._eg_grads(cx), self.opt_eg))
+            segs.append((lambda cx: (self._apply_eg(), self._d_real_grads(cx)), self.opt_d))
+        else:
+            segs.append((lambda cx: self._d_real_grads(cx), self.opt_d))
+        segs.append((lambda cx: (self._apply_d(), self._d_fake_grads(cx)), self.opt_d))
+        segs.append((lambda cx: (self._apply_d(), self._phase_scores(cx, average_bn=False)), None))
+        return segs
 
     def _iteration(self, images, c, z, do_eg=True):
         cx = self._begin(images, c, z)
@@ -357,15 +386,69 @@ class AliStepper:
         if masks is not None:
             with _dropout.injected_masks(masks):
                 return self._iteration(images, c, z, do_eg)
-        if not self.capture or self.world > 1:
+        if not self.capture:
             return self._iteration(images, c, z, do_eg)
-        return self._replay(images, c, z, do_eg)
+        try:
+            if self.world > 1 or self.segmented:
+                return self._replay_segments(images, c, z, do_eg)
+            return self._replay(images, c, z, do_eg)
+        except Exception as e:  # graph capture refused (driver / RCCL combination): keep training, eagerly
+            if self._graph is not None:
+                raise
+            import warnings
+            warnings.warn(f"AliStepper: HIP graph capture failed ({e!r}); continuing with eager launches")
+            self.capture = False
+            if self._capture_snapshot is not None:
+                self._restore(self._capture_snapshot)
+            return self._iteration(images, c, z, do_eg)
+
+    def _replay_segments(self, images, c, z, do_eg):
+        """Data-parallel replay: one HIP graph per segment, the gradient all-reduces in between launched eagerly."""
+        key = ("seg", tuple(images.shape), do_eg)
+        if self._graph is None or self._graph[0] != key:
+            st = {"images": images.clone(), "z": z.clone(), "c": {k: v.clone() for k, v in c.items()}}
+            snap = self._snapshot()
+            self._capture_snapshot = snap
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):          # warm-up outside capture (collectives included: all ranks do this)
+                self._iteration(st["images"], st["c"], st["z"], do_eg)
+            torch.cuda.current_stream().wait_stream(s)
+            self._restore(snap)
+            pool = torch.cuda.graph_pool_handle()
+            graphs, cx = [], None
+            for i, (fn, group) in enumerate(self._segments(do_eg)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    if i == 0:
+                        cx = self._begin(st["images"], st["c"], st["z"])
+                    fn(cx)
+                graphs.append((g, group))
+                if group is not None and self.world > 1:   # keep the ranks' collective sequences aligned while capturing
+                    dp.allreduce_sum_(group.grad, self.pg)
+            if self.world > 1:
+                dp.average_buffers_(self.bn_buffers, self.pg)
+            self._restore(snap)                 # capture executes nothing, but the eager collectives above ran
+            self._graph = (key, graphs, st, cx["out"])
+        _, graphs, st, res = self._graph
+        st["images"].copy_(images)
+        st["z"].copy_(z)
+        for k, v in c.items():
+            st["c"][k].copy_(v)
+        for g, group in graphs:
+            g.replay()
+            if group is not None and self.world > 1:
+                dp.allreduce_sum_(group.grad, self.pg)
+        if self.world > 1:
+            dp.average_buffers_(self.bn_buffers, self.pg)
+        return res
 
     def _replay(self, images, c, z, do_eg):
         key = (tuple(images.shape), do_eg)
         if self._graph is None or self._graph[0] != key:
             st = {"images": images.clone(), "z": z.clone(), "c": {k: v.clone() for k, v in c.items()}}
             snap = self._snapshot()
+            self._capture_snapshot = snap
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):          # warm-up outside capture: packs, workspace, plans
@@ -373,7 +456,7 @@ class AliStepper:
             torch.cuda.current_stream().wait_stream(s)
             self._restore(snap)                 # the warm-up must not count as a training iteration
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 res = self._iteration(st["images"], st["c"], st["z"], do_eg)
             self._graph = (key, graph, st, res)
         _, graph, st, res = self._graph

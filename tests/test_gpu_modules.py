@@ -470,3 +470,21 @@ def test_spect_stepper_iteration_vs_oracle(family, d, B):
         err = (wp - wo).abs()
         assert (err > 0.05 * lr).double().mean().item() < 5e-3, nm
         assert err.mean().item() <= 0.02 * lr, (nm, err.mean().item())
+
+
+def test_segmented_graph_replay_equals_eager():
+    """The data-parallel replay (one HIP graph per segment, collectives in between) on one rank == eager."""
+    import ali_hip
+    ali_hip.manual_seed(77)
+    _, (E1, G1, D1), eager, batches = _stepper_setup(capture=False)
+    ali_hip.manual_seed(77)
+    _, (E2, G2, D2), seg, _ = _stepper_setup(capture=True)
+    seg.segmented = True
+    for images, c, z in batches:
+        r1 = eager.step(images.cuda(), to_dev(c), z.cuda())
+        r2 = seg.step(images.cuda(), to_dev(c), z.cuda())
+        for k in r1:
+            assert r1[k].item() == r2[k].item(), (k, r1[k].item(), r2[k].item())
+    assert torch.equal(eager.opt_d.flat, seg.opt_d.flat) and torch.equal(eager.opt_eg.flat, seg.opt_eg.flat)
+    for (k, v1), (_, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
+        assert torch.equal(v1, v2), k
