@@ -12,11 +12,13 @@ import torch
 
 from . import ops
 
-_state = {"seed": 0x5EED, "offset": 0, "inject": None, "pos": 0, "dev_counter": None}
+_state = {"seed": 0x5EED, "offset": 0, "inject": None, "pos": 0, "dev_counter": None,
+          "plan": None, "record": None, "req": 0}
 
 
 def manual_seed(seed: int):
     _state["seed"], _state["offset"] = int(seed), 0
+    _state["plan"] = _state["record"] = None
 
 
 @contextlib.contextmanager
@@ -29,10 +31,39 @@ def injected_masks(masks):
         _state["inject"], _state["pos"] = prev
 
 
-def begin_iteration(dev_counter):
+def begin_iteration(dev_counter, owner=None):
     """Stepper hook: masks of this iteration are keyed by the device-side iteration counter (graph replays
-    read its current value) and by positions that restart at 0 every iteration."""
-    _state["dev_counter"], _state["offset"] = dev_counter, 0
+    read its current value) and by positions that restart at 0 every iteration.
+
+    The first iteration of a stepper records its (B, C, p) request sequence; from then on all masks of an
+    iteration are produced by ONE launch (``ali_dropout_mask_multi``, bit-identical draws) and handed out as views."""
+    _state["dev_counter"], _state["offset"], _state["req"] = dev_counter, 0, 0
+    plan = _state["plan"]
+    if plan is not None and plan["owner"] is not owner:
+        plan = _state["plan"] = None
+    if _state["inject"] is not None:
+        _state["record"] = None
+        return
+    if plan is None:
+        _state["record"] = {"owner": owner, "req": []}
+        return
+    _state["record"] = None
+    ops.dropout_mask_multi(_state["seed"], dev_counter, plan["ends"], plan["ps"], plan["buf"])
+
+
+def end_iteration():
+    rec = _state["record"]
+    _state["record"] = None
+    if rec is None or not rec["req"] or len(rec["req"]) > 64:
+        return
+    ends, ps, off = [], [], 0
+    for B, C, p in rec["req"]:
+        off += B * C
+        ends.append(off)
+        ps.append(p)
+    dev = rec["device"]
+    _state["plan"] = {"owner": rec["owner"], "req": rec["req"], "ends": ends, "ps": ps,
+                      "buf": torch.empty(off, dtype=torch.float32, device=dev)}
 
 
 def masks_consumed() -> int:
@@ -49,6 +80,18 @@ def next_mask(B: int, C: int, p: float, device) -> torch.Tensor:
         if tuple(m.shape) != (B, C):
             raise RuntimeError(f"injected mask shape {tuple(m.shape)} != {(B, C)}")
         return m.to(device=device, dtype=torch.float32).contiguous()
+    plan, rec = _state["plan"], _state["record"]
+    if plan is not None and rec is None:
+        i = _state["req"]
+        if i < len(plan["req"]) and plan["req"][i] == (B, C, p):
+            lo = plan["ends"][i] - B * C
+            _state["req"] = i + 1
+            _state["offset"] = plan["ends"][i]
+            return plan["buf"][lo:lo + B * C].view(B, C)
+        _state["plan"] = None          # request sequence changed: fall back to one launch per mask
     m = ops.dropout_mask(_state["seed"], _state["offset"], p, B, C, device, _state["dev_counter"])
     _state["offset"] += B * C
+    if rec is not None:
+        rec["req"].append((B, C, p))
+        rec["device"] = device
     return m

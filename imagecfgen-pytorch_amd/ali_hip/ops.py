@@ -236,6 +236,17 @@ def dropout_mask(seed, offset, p, B, C, device, dev_counter=None):
     return out
 
 
+def dropout_mask_multi(seed, dev_counter, seg_end, seg_p, out):
+    """one launch for all masks of an iteration; seg_end / seg_p are host lists."""
+    lib = _lib.load()
+    n = len(seg_end)
+    ends = (ctypes.c_int64 * n)(*seg_end)
+    ps = (ctypes.c_float * n)(*seg_p)
+    ctr = None if dev_counter is None else c_void_p(dev_counter.data_ptr())
+    _lib.check(lib.ali_dropout_mask_multi(seed, ctr, ends, ps, n, _chk(out), _stream()), "ali_dropout_mask_multi")
+    return out
+
+
 def bn_stats(x, mask, B, rows_per_img, C, gamma, beta, running_mean, running_var, momentum, eps, training):
     lib = _lib.load()
     ws = workspace(x.device)

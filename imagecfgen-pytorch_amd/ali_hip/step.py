@@ -203,7 +203,7 @@ class AliStepper:
     def _begin(self, images, c, z):
         B = images.shape[0]
         self.iter_t += 1
-        _dropout.begin_iteration(self.iter_t)
+        _dropout.begin_iteration(self.iter_t, owner=self)
         idx, cont, onehots = self.family.conditioning(c)
         return {"images": images, "B": B, "idx": idx, "cont": cont, "onehots": onehots,
                 "zin": z.reshape(B, -1).float().contiguous(), "out": {}}
@@ -301,6 +301,7 @@ class AliStepper:
         de, _ = self._d_forward(x0d, cx["n_log"], cx["ex"], False)
         cx["out"]["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
         cx["out"]["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
+        _dropout.end_iteration()
         if self.world > 1 and average_bn:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
             dp.average_buffers_(self.bn_buffers, self.pg)

@@ -109,6 +109,24 @@ __global__ void dropout_mask_kernel(uint64_t seed, uint64_t offset, const long l
   }
 }
 
+// all Dropout2d masks of one iteration in one launch: element i belongs to the segment whose end offset is the first
+// one > i and uses that segment's p; the draw for global index i is the same as dropout_mask_kernel(offset=0) gives
+struct MaskSegs { long long end[64]; float p[64]; int n; };
+__global__ void dropout_mask_multi_kernel(uint64_t seed, const long long* __restrict__ dev_counter, MaskSegs segs,
+                                          float* __restrict__ out, long long total) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  const uint64_t key = mix64(mix64(seed) ^ (dev_counter ? (uint64_t)dev_counter[0] * 0xD1B54A32D192ED03ull : 0ull));
+  for (; i < total; i += step) {
+    int s = 0;
+    while (s < segs.n - 1 && i >= segs.end[s]) ++s;
+    const float p = segs.p[s];
+    const uint64_t r = mix64(key ^ (uint64_t)i);
+    const float u = (float)(r >> 40) * (1.f / 16777216.f);
+    out[i] = u < 1.f - p ? 1.f / (1.f - p) : 0.f;
+  }
+}
+
 // ---- BatchNorm2d ------------------------------------------------------------
 // stage 1: per-block partial (sum, sumsq) of x~ = x*mask per channel -> part[nblk][2][C]
 __global__ void bn_stats_partial_kernel(const float* __restrict__ x, const float* __restrict__ mask, long long rows,
@@ -409,6 +427,22 @@ extern "C" int ali_dropout_mask(uint64_t seed, uint64_t offset, const int64_t* d
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), seed, offset,
                      reinterpret_cast<const long long*>(dev_counter), p, out, (long long)n);
   return check_launch("dropout_mask_kernel");
+}
+
+extern "C" int ali_dropout_mask_multi(uint64_t seed, const int64_t* dev_counter, const int64_t* seg_end,
+                                      const float* seg_p, int32_t n_seg, float* out, ali_stream_t stream) {
+  if (!seg_end || !seg_p || !out || n_seg < 1 || n_seg > 64) { set_error("ali_dropout_mask_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+  MaskSegs segs;
+  long long prev = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    if (seg_end[i] <= prev || !(seg_p[i] >= 0.f && seg_p[i] < 1.f)) { set_error("ali_dropout_mask_multi: bad segment"); return ALI_ERR_BAD_ARG; }
+    segs.end[i] = prev = seg_end[i];
+    segs.p[i] = seg_p[i];
+  }
+  segs.n = n_seg;
+  hipLaunchKernelGGL(dropout_mask_multi_kernel, dim3(ew_grid(prev)), dim3(kEwBlock), 0, ST(stream), seed,
+                     reinterpret_cast<const long long*>(dev_counter), segs, out, prev);
+  return check_launch("dropout_mask_multi_kernel");
 }
 
 extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_t rows_per_img, int32_t C,

@@ -191,6 +191,190 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WDesc d) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path (both channel strides % 4 == 0): same loop discipline as gconv.hip -- fp32 MFMA shares the vector issue
+// path, so VALU work per k-tile is kept minimal (buffer loads with hardware range check, float-reciprocal pixel
+// decode) and every LDS / global instruction sits behind an individual MFMA.  k-tile = 32 pixels.
+constexpr int WBK2 = 32;
+
+__device__ __forceinline__ void w_divmod(int m, int dv, float rcp, int& q, int& r) {
+  q = (int)((float)m * rcp);
+  r = m - q * dv;
+  if (r < 0) { --q; r += dv; }
+  else if (r >= dv) { ++q; r -= dv; }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsigned x_bytes, unsigned dy_bytes) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int A4 = BM / 4, B4 = BN / 4;            // float4 per pixel row
+  constexpr int AROWS = 256 / A4, BROWS = 256 / B4;  // pixel rows covered per pass
+  constexpr int AP = WBK2 / AROWS, BP = WBK2 / BROWS;
+  constexpr int NL = AP + BP;
+  constexpr int NMF = (WBK2 / 2) * TM * TN;
+  static_assert(AP >= 1 && BP >= 1, "tile");
+
+  __shared__ __attribute__((aligned(16))) float As[2][WBK2 * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WBK2 * LDB];
+  __shared__ long long s_rowdst[BM];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int pix_begin = blockIdx.z * d.pix_per_split;
+  const int pix_end = min(d.npix, pix_begin + d.pix_per_split);
+  const int PQ = d.P * d.Q;
+  const float rPQ = 1.0f / (float)PQ, rQ = 1.0f / (float)d.Q;
+
+  for (int r = t; r < BM; r += 256) {
+    const int m = m0 + r;
+    long long off = -1;
+    if (m < d.Mtot) {
+      const int tap = m / d.Cg, gc = m - tap * d.Cg;
+      if (gc < d.Cg_log) off = gc * d.s_gc + tap * d.s_tap;
+    }
+    s_rowdst[r] = off;
+  }
+  // this thread's A column: tap (dh, dw) and gathered channel are fixed
+  const int a4 = t % A4, arow0 = t / A4;
+  const int mA = m0 + a4 * 4;
+  const bool a_ok = mA < d.Mtot;
+  const int tapA = a_ok ? mA / d.Cg : 0;
+  const int gcA = mA - tapA * d.Cg;
+  const int dhA = tapA / d.S - d.pad, dwA = tapA % d.S - d.pad;
+  const int b4 = t % B4, brow0 = t / B4;
+  const int nB = n0 + b4 * 4;
+  const bool b_ok = nB < d.Cd;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)d.x, 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)d.dy, 0, dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  __syncthreads();
+
+  f32x4 ra[AP], rb[BP];
+  auto load_a = [&](int pix0, int i) {
+    const int pix = pix0 + arow0 + i * AROWS;
+    unsigned off = OOB;
+    if (a_ok && pix < pix_end) {
+      int b, rem, p, q;
+      w_divmod(pix, PQ, rPQ, b, rem);
+      w_divmod(rem, d.Q, rQ, p, q);
+      const int ih = p * d.stride + dhA, iw = q * d.stride + dwA;
+      if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+        off = (unsigned)(((b * d.H + ih) * d.W + iw) * d.Cg + gcA) * 4u;
+    }
+    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0));
+  };
+  auto load_b = [&](int pix0, int j) {
+    const int pix = pix0 + brow0 + j * BROWS;
+    const unsigned off = (b_ok && pix < pix_end) ? (unsigned)(pix * d.Cd + nB) * 4u : OOB;
+    rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf][(arow0 + i * AROWS) * LDA + a4 * 4]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(brow0 + j * BROWS) * LDB + b4 * 4]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (pix_begin < pix_end) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) load_a(pix_begin, i);
+#pragma unroll
+    for (int j = 0; j < BP; ++j) load_b(pix_begin, j);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    const int lcol = lane & 31, lh = lane >> 5;
+    float fa[2][TM], fb[2][TN];
+    for (int pix0 = pix_begin; pix0 < pix_end; pix0 += WBK2) {
+      const int nxt = pix0 + WBK2;   // rows >= pix_end load zeros (range-checked offsets)
+      const float* Ac = &As[buf][lh * LDA + wm * WM + lcol];
+      const float* Bc = &Bs[buf][lh * LDB + wn * WN + lcol];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[0][i] = Ac[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = Bc[j * 32];
+#pragma unroll
+      for (int s = 0; s < NMF; ++s) {
+        const int ks = s / (TM * TN), i = (s / TN) % TM, j = s % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          constexpr int Q = NMF / 4;
+          if (s < Q) {
+#pragma unroll
+            for (int x = 0; x < NL; ++x) {
+              if ((x * Q) / NL != s) continue;
+              if (x < AP) load_a(nxt, x); else load_b(nxt, x - AP);
+            }
+          }
+        }
+        {  // fragments of k-step ks+1: TM+TN single-float reads, one behind each MFMA of step ks
+          const int sg = s - ks * TM * TN;
+          if (ks + 1 < WBK2 / 2 && sg < TM + TN) {
+            if (sg < TM) fa[(ks + 1) & 1][sg] = Ac[(ks + 1) * 2 * LDA + sg * 32];
+            else fb[(ks + 1) & 1][sg - TM] = Bc[(ks + 1) * 2 * LDB + (sg - TM) * 32];
+          }
+          if (TM * TN < TM + TN && ks + 1 < WBK2 / 2 && sg == TM * TN - 1) {   // 1x1 wave tile: 2 reads behind 1 MFMA
+#pragma unroll
+            for (int x = TM * TN; x < TM + TN; ++x) {
+              if (x < TM) fa[(ks + 1) & 1][x] = Ac[(ks + 1) * 2 * LDA + x * 32];
+              else fb[(ks + 1) & 1][x - TM] = Bc[(ks + 1) * 2 * LDB + (x - TM) * 32];
+            }
+          }
+        }
+        {
+          constexpr int Q = NMF / 4;
+          const int sw = s - 3 * Q;
+          if (sw >= 0) {
+#pragma unroll
+            for (int x = 0; x < NL; ++x) {
+              if ((x * Q) / NL != sw) continue;
+              if (x < AP) *reinterpret_cast<f32x4*>(&As[buf ^ 1][(arow0 + x * AROWS) * LDA + a4 * 4]) = ra[x];
+              else *reinterpret_cast<f32x4*>(&Bs[buf ^ 1][(brow0 + (x - AP) * BROWS) * LDB + b4 * 4]) = rb[x - AP];
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  const bool partial = d.splitk > 1;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 32 + (lane & 31);
+    if (n >= (partial ? d.Cd : d.Cd_log)) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float v = acc[i][j][r];
+        if (partial) {
+          const int m = m0 + row;
+          if (m < d.Mtot) d.ws[((long long)blockIdx.z * d.Mtot + m) * d.Cd + n] = v;
+        } else {
+          const long long off = s_rowdst[row];
+          if (off >= 0) d.dst[off + n * d.s_dc] = v;
+        }
+      }
+    }
+  }
+}
+
 // dst[dc*s_dc + gc*s_gc + tap*s_tap] = sum_s ws[s][tap*Cg+gc][dc]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log,
                                     int Cd_log, long long s_dc, long long s_gc, long long s_tap,
@@ -230,23 +414,41 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   d.Mtot = g->R * g->S * g->C;
   d.npix = g->B * g->P * g->Q;
   const bool veca = (g->C % 4) == 0, vecb = (g->K % 4) == 0;
-  const int bn = g->K > 64 ? 128 : (g->K > 32 ? 64 : 32);
-  const int bm = 128;
+  const long long x_elems = (long long)g->B * g->H * g->W * g->C, dy_elems = (long long)g->B * g->P * g->Q * g->K;
+  const bool fast = veca && vecb && x_elems < (1LL << 30) && dy_elems < (1LL << 30) && d.npix < (1 << 24);
+  int bn = g->K > 64 ? 128 : (g->K > 32 ? 64 : 32);
+  int bm = 128;
+  if (fast) {
+    // more, smaller tiles while the grid is shallow (see gconv.hip: waits are only hidden by co-resident waves)
+    const long long b64 = (long long)((d.Mtot + 63) / 64) * ((g->K + 63) / 64);
+    if (g->K > 32 && b64 <= 2 * kNumCU) { bm = 64; bn = 64; }
+    else if (g->K > 64) { bm = 128; bn = 128; }
+    else if (g->K > 32) { bm = 128; bn = 64; }
+    else { bm = 128; bn = 32; }
+  }
+  const int wbk = fast ? WBK2 : WBK;
   const int tiles_m = (d.Mtot + bm - 1) / bm, tiles_n = (g->K + bn - 1) / bn;
   const long long blocks = (long long)tiles_m * tiles_n;
   int S = 1;
-  const int nkt = (d.npix + WBK - 1) / WBK;
-  if (blocks < 2 * kNumCU && nkt >= 8) {
-    S = (int)((2 * kNumCU + blocks - 1) / blocks);
-    if (S > nkt / 4) S = nkt / 4;
-    if (S > 64) S = 64;
+  const int nkt = (d.npix + wbk - 1) / wbk;
+  if (blocks < 4 * kNumCU && nkt >= 4) {
+    S = (int)((4 * kNumCU + blocks - 1) / blocks);
+    if (S > nkt / 2) S = nkt / 2;
+    if (S > 128) S = 128;
     while (S > 1 && (size_t)S * d.Mtot * g->K * sizeof(float) > ws_bytes) --S;
     if (S < 1) S = 1;
   }
   d.splitk = S;
   int per = (nkt + S - 1) / S;
-  d.pix_per_split = per * WBK;
+  d.pix_per_split = per * wbk;
   dim3 grid(tiles_m, tiles_n, S), block(256);
+  if (fast) {
+    const unsigned xb = (unsigned)(x_elems * 4), yb = (unsigned)(dy_elems * 4);
+    if (bm == 64) hipLaunchKernelGGL((wgrad_fast_kernel<64, 64, 2, 2>), grid, block, 0, stream, d, xb, yb);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_fast_kernel<128, 128, 2, 2>), grid, block, 0, stream, d, xb, yb);
+    else if (bn == 64) hipLaunchKernelGGL((wgrad_fast_kernel<128, 64, 2, 2>), grid, block, 0, stream, d, xb, yb);
+    else hipLaunchKernelGGL((wgrad_fast_kernel<128, 32, 4, 1>), grid, block, 0, stream, d, xb, yb);
+  } else {
 #define WLAUNCH(BN_, WMM, WNN)                                                                        \
   do {                                                                                                 \
     if (veca && vecb) hipLaunchKernelGGL((wgrad_kernel<128, BN_, WMM, WNN, true, true>), grid, block, 0, stream, d);   \
@@ -254,10 +456,11 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     else if (vecb) hipLaunchKernelGGL((wgrad_kernel<128, BN_, WMM, WNN, false, true>), grid, block, 0, stream, d);     \
     else hipLaunchKernelGGL((wgrad_kernel<128, BN_, WMM, WNN, false, false>), grid, block, 0, stream, d);               \
   } while (0)
-  if (bn == 128) WLAUNCH(128, 2, 2);
-  else if (bn == 64) WLAUNCH(64, 2, 2);
-  else WLAUNCH(32, 4, 1);
+    if (bn == 128) WLAUNCH(128, 2, 2);
+    else if (bn == 64) WLAUNCH(64, 2, 2);
+    else WLAUNCH(32, 4, 1);
 #undef WLAUNCH
+  }
   int rc = check_launch("wgrad_kernel");
   if (rc) return rc;
   if (S > 1) {

@@ -127,6 +127,11 @@ int ali_rowmask_mul(const float* x, const float* mask, float* out, int32_t B, in
 int ali_dropout_mask(uint64_t seed, uint64_t offset, const int64_t* dev_counter, float p, float* out, int64_t n,
                      ali_stream_t stream);
 
+/* All masks of one iteration in one launch: segment j covers elements [seg_end[j-1], seg_end[j]) with drop
+ * probability seg_p[j] (host arrays, n_seg <= 64); element i gets the draw ali_dropout_mask(offset 0) gives index i. */
+int ali_dropout_mask_multi(uint64_t seed, const int64_t* dev_counter, const int64_t* seg_end, const float* seg_p,
+                           int32_t n_seg, float* out, ali_stream_t stream);
+
 /* nn.BatchNorm2d in training / eval mode (mnist.py:111,114,118,122).
  * stats: per-channel batch mean / biased var of (mask ? x*mask : x), running
  * stats updated with `momentum` and the unbiased variance when `training`;
