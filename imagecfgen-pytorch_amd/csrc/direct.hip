@@ -201,6 +201,79 @@ __global__ __launch_bounds__(256) void tconv1_wgrad_kernel(const T1Desc d, int n
   }
 }
 
+// Register-blocked variant (needs 256/K >= R): thread = (k, tap row r) keeps acc[NC][S]; per 4 consecutive pixels it
+// reads 4 big values and, per small channel, one 8-float row segment, for 4*S*NC FMAs (7 FMAs per LDS read instead of 1).
+template <int NC, int S_>
+__global__ __launch_bounds__(256) void tconv1_wgrad_rb_kernel(const T1Desc d, int nitems, int bands) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = d.K;
+  const int SR = T1W_RB + d.R - 1;
+  const int Q4 = (d.Q + 3) & ~3;
+  const int SW = (Q4 + S_ - 1 + 3) & ~3;   // row stride of the staged small band (16-byte aligned rows)
+  float* bigl = smem;                      // [T1W_RB][Q4][K], zero padded
+  float* sml = smem + T1W_RB * Q4 * K;     // [NC][SR][SW], zero padded
+  const int t = threadIdx.x;
+  const int k = t % K, r = t / K;
+  const bool active = r < d.R;
+  float acc[NC][S_];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int s = 0; s < S_; ++s) acc[c][s] = 0.f;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / bands, p0 = (item % bands) * T1W_RB;
+    const int rows = min(T1W_RB, d.P - p0);
+    __syncthreads();
+    for (int i = t; i < T1W_RB * Q4 * (K / 4); i += 256) {
+      const int c4 = i % (K / 4);
+      const int pix = i / (K / 4);
+      const int pr = pix / Q4, q = pix % Q4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pr < rows && q < d.Q)
+        v = *reinterpret_cast<const f32x4*>(d.big + ((long long)(b * d.P + p0 + pr) * d.Q + q) * K + c4 * 4);
+      *reinterpret_cast<f32x4*>(bigl + pix * K + c4 * 4) = v;
+    }
+    for (int i = t; i < NC * SR * SW; i += 256) {
+      const int c = i / (SR * SW), rem = i % (SR * SW);
+      const int sr = rem / SW, sc = rem % SW;
+      const int ih = p0 + sr - d.pad, iw = sc - d.pad;
+      float v = 0.f;
+      if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+        v = d.small[((long long)(b * d.H + ih) * d.W + iw) * d.sstride + c];
+      sml[i] = v;
+    }
+    __syncthreads();
+    if (active) {
+      for (int pr = 0; pr < rows; ++pr) {
+        for (int q = 0; q < Q4; q += 4) {
+          float bv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[j] = bigl[((pr * Q4) + q + j) * K + k];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float* sp = sml + (c * SR + pr + r) * SW + q;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            const float seg[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+            for (int s = 0; s < S_; ++s)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[c][s] += bv[j] * seg[j + s];
+          }
+        }
+      }
+    }
+  }
+  if (active) {
+    const int T = d.R * d.S;
+    float* part = d.part + (long long)blockIdx.x * (NC * K * T);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int s = 0; s < S_; ++s) part[(c * K + k) * T + r * S_ + s] = acc[c][s];
+  }
+}
+
 // out[c*s_c + k*s_k + tap*s_tap] = sum_b part[b][(c*K + k)*T + tap]   (one wave per output, fixed order)
 __global__ void t1_reduce_kernel(const float* __restrict__ part, int nblk, int K, int T, int NC, float* __restrict__ out,
                                  long long s_k, long long s_tap, long long s_c) {
@@ -286,14 +359,26 @@ extern "C" int ali_tconv1_wgrad(const float* big, const float* small, int32_t ss
   T1Desc d = {};
   d.big = big; d.small = small; d.sstride = sstride; d.part = reinterpret_cast<float*>(ws);
   d.B = B; d.P = P; d.Q = Q; d.K = K; d.H = H; d.W = W; d.R = R; d.S = S; d.pad = pad;
-  const size_t lds = ((size_t)T1W_RB * Q * K + (size_t)nc * (T1W_RB + R - 1) * (Q + S - 1)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  const int Q4 = (Q + 3) & ~3;
+  const int SWp = (Q4 + S - 1 + 3) & ~3;
+  const size_t lds_rb = ((size_t)T1W_RB * Q4 * K + (size_t)nc * (T1W_RB + R - 1) * SWp) * sizeof(float);
+  const bool rb = (256 / K) >= R && S <= 5 && S >= 3 && lds_rb <= 64 * 1024 && (nc == 1 || nc == 5 || nc == 7);
+  if (rb) {
+#define WRB(NC_, S_) hipLaunchKernelGGL((tconv1_wgrad_rb_kernel<NC_, S_>), dim3(nblk), dim3(256), lds_rb, st, d, nitems, bands)
+    if (nc == 1 && S == 3) WRB(1, 3); else if (nc == 1 && S == 4) WRB(1, 4); else if (nc == 1) WRB(1, 5);
+    else if (nc == 5 && S == 3) WRB(5, 3); else if (nc == 5 && S == 4) WRB(5, 4); else if (nc == 5) WRB(5, 5);
+    else if (nc == 7 && S == 3) WRB(7, 3); else if (nc == 7 && S == 4) WRB(7, 4); else WRB(7, 5);
+#undef WRB
+  } else {
+  const size_t lds = ((size_t)T1W_RB * Q * K + (size_t)nc * (T1W_RB + R - 1) * (Q + S - 1)) * sizeof(float);
 #define WG(NC_) hipLaunchKernelGGL((tconv1_wgrad_kernel<NC_>), dim3(nblk), dim3(256), lds, st, d, nitems, bands)
   switch (nc) {
     case 1: WG(1); break; case 2: WG(2); break; case 3: WG(3); break; case 4: WG(4); break;
     case 5: WG(5); break; case 6: WG(6); break; case 7: WG(7); break; default: WG(8); break;
   }
 #undef WG
+  }
   hipLaunchKernelGGL(t1_reduce_kernel, dim3(nc * K * T), dim3(64), 0, st, d.part, nblk, K, T, nc, dw, (long long)s_k,
                      (long long)s_tap, (long long)s_c);
   return check_launch("tconv1_wgrad");

@@ -86,7 +86,9 @@ __device__ __forceinline__ void fast_divmod(int m, int dv, float rcp, int& q, in
   else if (r >= dv) { ++q; r -= dv; }
 }
 
-// MODE 0: scalar gathers (channel stride % 4 != 0); 1: 16-byte gathers, tap per thread; 2: uniform-tap fast path
+// MODE 0: scalar gathers (channel stride % 4 != 0); 1: 16-byte gathers, tap per thread (division); 2: uniform-tap fast
+// path (channel stride % 32 == 0); 3: fast path for channel stride 4 / 8 / 16 (first layers): a k-tile holds 32/C whole
+// taps, the tap of a thread's 16-byte chunk is a shift, its constants a per-thread LDS read
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
 __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   __shared__ int s_rowoff[BM];  // element offset of the row's output pixel (host guarantees < 2^31), -1 = none
   __shared__ int s_rowimg[BM];
   __shared__ int s_tap[kMaxTaps];                                  // dh | dw<<8 | wt<<16 (generic path)
-  __shared__ __attribute__((aligned(16))) int s_live[kMaxTaps][4]; // per live tap {doff, woff, tap bit, 0} (bytes)
+  __shared__ __attribute__((aligned(16))) int s_live[kMaxTaps + 8][4]; // per (live) tap {doff, woff, tap bit, 0} (bytes)
   __shared__ unsigned s_tapmask;
 
   const int t = threadIdx.x;
@@ -200,10 +202,20 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   const float* Bb = &Bs[0][(wn * WN + lrow) * LDK + lh * 4];
   f32x4 fa[2][TM], fb[2][TN];
 
-  if (MODE == 2) {
-    // ================= uniform-tap fast path =================
+  if (MODE >= 2) {
+    // ================= uniform-tap fast path (MODE 2) / small power-of-two channel stride (MODE 3) =================
     // live taps, compacted: {byte offset into the activation, byte offset into the weight row, tap bit}
-    if (t < ntaps && ((tapmask >> t) & 1u)) {
+    if (MODE == 3) {   // all taps in order (no compaction); entries past the last tap are dead
+      if (t < kMaxTaps + 8) {
+        const bool live = t < ntaps && ((tapmask >> t) & 1u);
+        const int tv = s_tap[t < kMaxTaps ? t : 0];
+        const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
+        s_live[t][0] = ((dh * Win + dw) * Cin) * 4;
+        s_live[t][1] = live ? (wt * Cin) * 4 : (int)0xFFFFFF00u;
+        s_live[t][2] = live ? (int)(1u << t) : 0;
+        s_live[t][3] = 0;
+      }
+    } else if (t < ntaps && ((tapmask >> t) & 1u)) {
       const int pos = __popc(tapmask & ((1u << t) - 1u));
       const int tv = s_tap[t];
       const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
@@ -213,8 +225,11 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
       s_live[pos][3] = 0;
     }
     __syncthreads();
-    const int cpt = Cin / BK;
-    const int nlive = __popc(tapmask);
+    const int tpt = MODE == 3 ? BK / Cin : 1;                 // whole taps per k-tile (MODE 3)
+    const int tsub = MODE == 3 ? (c4 * 4) / Cin : 0;          // this thread's tap inside the k-tile
+    const int ccol = MODE == 3 ? (c4 * 4) % Cin : c4 * 4;     // this thread's channel offset inside the tap / chunk
+    const int cpt = MODE == 3 ? 1 : Cin / BK;
+    const int nlive = MODE == 3 ? (ntaps + tpt - 1) / tpt : __popc(tapmask);
     const int total = nlive * cpt;
     const int per = (total + d.splitk - 1) / d.splitk;
     const int qb = blockIdx.z * per;
@@ -225,16 +240,18 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     constexpr unsigned OOB = 0xFFFFFF00u;  // >= num_records: the load returns 0
     unsigned aoffB[AP], woffB[BP];
 #pragma unroll
-    for (int i = 0; i < AP; ++i) aoffB[i] = (unsigned)(aoff[i] + c4 * 4) * 4u;
+    for (int i = 0; i < AP; ++i) aoffB[i] = (unsigned)(aoff[i] + ccol) * 4u;
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
       const int n = n0 + r0 + 32 * j;
-      woffB[j] = n < d.Cout ? (unsigned)(((long long)n * d.ldw + c4 * 4) * 4) : OOB;
+      woffB[j] = n < d.Cout ? (unsigned)(((long long)n * d.ldw + ccol) * 4) : OOB;
     }
     struct Ctx { int doff, woff; unsigned bit; };
-    auto tile_ctx = [&](int li, int ch, bool live) -> Ctx {
-      const int lc = li < nlive ? li : (nlive > 0 ? nlive - 1 : 0);
+    auto tile_ctx = [&](int li, int ch, bool live) -> Ctx {   // MODE 3: a per-thread LDS read; MODE 2: a broadcast
+      const int lc = MODE == 3 ? (li < nlive ? li * tpt + tsub : 0)
+                               : (li < nlive ? li : (nlive > 0 ? nlive - 1 : 0));
       const int4 ti = *reinterpret_cast<const int4*>(&s_live[lc][0]);
+      if (MODE == 3 && li >= nlive) live = false;
       Ctx cx;
       cx.doff = ti.x + ch * (BK * 4);
       cx.woff = live ? ti.y + ch * (BK * 4) : (int)OOB;
@@ -533,6 +550,7 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   }
   const int max_nkt = (max_taps * d.Cin + BK - 1) / BK;
   const bool uni = vec && (d.Cin % BK) == 0;
+  const bool pow2 = vec && (d.Cin == 4 || d.Cin == 8 || d.Cin == 16) && max_taps <= kMaxTaps;
   TileCfg tc = pick_tile(Mtot, d.Cout);
   if (!vec && tc.bn == 128) tc.bn = 64;
   {
@@ -581,6 +599,7 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
 #define LAUNCH(BM_, BN_, WMM, WNN)                                                                    \
   do {                                                                                                  \
     if (uni) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2>), grid, block, 0, stream, d);      \
+    else if (pow2) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 3>), grid, block, 0, stream, d);  \
     else if (vec) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 1>), grid, block, 0, stream, d); \
     else hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 0>), grid, block, 0, stream, d);          \
   } while (0)
