@@ -37,6 +37,8 @@ SIGNATURES = {
                                       c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "ali_pack_weights": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
                                    c_void_p]),
+    "ali_pack_weights_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32),
+                                         POINTER(c_int64), c_void_p]),
     "ali_act_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "ali_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ali_rowmask_mul": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

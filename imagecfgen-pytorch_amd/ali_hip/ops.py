@@ -193,7 +193,47 @@ def tconv1_wgrad(big, small, sstride, nc, dw, s_k, s_tap, s_c, B, P, Q, K, R, S,
     return dw
 
 
+_PACK_BATCH = None
+
+
+class batched_packs:
+    """Collect the ``pack_weights`` calls issued inside the block and run them as ONE launch (at most 40 jobs per
+    launch; a job that reads the destination of a pending job flushes first)."""
+
+    def __enter__(self):
+        global _PACK_BATCH
+        self.prev, _PACK_BATCH = _PACK_BATCH, []
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_BATCH
+        _flush_packs()
+        _PACK_BATCH = self.prev
+
+
+def _flush_packs():
+    jobs = _PACK_BATCH
+    if not jobs:
+        return
+    lib = _lib.load()
+    for lo in range(0, len(jobs), 40):
+        part = jobs[lo:lo + 40]
+        n = len(part)
+        srcs = (c_void_p * n)(*[j[0].data_ptr() for j in part])
+        dsts = (c_void_p * n)(*[j[1].data_ptr() for j in part])
+        dims = (ctypes.c_int32 * (4 * n))(*[v for j in part for v in j[2:6]])
+        strides = (ctypes.c_int64 * (3 * n))(*[v for j in part for v in j[6:9]])
+        _lib.check(lib.ali_pack_weights_multi(n, srcs, dsts, dims, strides, _stream()), "ali_pack_weights_multi")
+    jobs.clear()
+
+
 def pack_weights(src, dst, N, T, C, Cpad, s_n, s_tap, s_c):
+    if _PACK_BATCH is not None:
+        _chk(src, "src"), _chk(dst, "dst")
+        if any(j[1].data_ptr() == src.data_ptr() for j in _PACK_BATCH):
+            _flush_packs()
+        _PACK_BATCH.append((src, dst, N, T, C, Cpad, s_n, s_tap, s_c))
+        return dst
     lib = _lib.load()
     _lib.check(lib.ali_pack_weights(_chk(src, "src"), _chk(dst, "dst"), N, T, C, Cpad, s_n, s_tap, s_c, _stream()),
                "ali_pack_weights")

@@ -240,8 +240,9 @@ class AliStepper:
 
     def _apply_eg(self):
         self.opt_eg.adam(1.0 / self.world)
-        self.pE.cache.refresh()
-        self.pG.cache.refresh()
+        with ops.batched_packs():
+            self.pE.cache.refresh()
+            self.pG.cache.refresh()
 
     def _apply_d(self):
         self.opt_d.adam(1.0 / self.world)
@@ -376,9 +377,10 @@ class AliStepper:
             pl.cache.refresh()
 
     def _refresh_d(self):
-        self.pDx.cache.refresh()
-        self.pDz.cache.refresh()
-        self.pDxz.cache.refresh()
+        with ops.batched_packs():
+            self.pDx.cache.refresh()
+            self.pDz.cache.refresh()
+            self.pDxz.cache.refresh()
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()

@@ -30,6 +30,26 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// several re-layout jobs in one launch (the weight packs refreshed after an Adam step)
+struct PackJob { const float* src; float* dst; int N, T, C, Cpad; long long s_n, s_tap, s_c; int blk0; };
+struct PackJobs { PackJob j[40]; int n; };
+__global__ void pack_weights_multi_kernel(PackJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].blk0) ++k;
+  const PackJob& J = jobs.j[k];
+  const int nblk = (k + 1 < jobs.n ? jobs.j[k + 1].blk0 : (int)gridDim.x) - J.blk0;
+  const long long total = (long long)J.N * J.T * J.Cpad;
+  long long i = (long long)((int)blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
+  const long long step = (long long)nblk * blockDim.x;
+  for (; i < total; i += step) {
+    const int c = (int)(i % J.Cpad);
+    const long long nt = i / J.Cpad;
+    const int tp = (int)(nt % J.T);
+    const long long n = nt / J.T;
+    J.dst[i] = c < J.C ? J.src[n * J.s_n + tp * J.s_tap + c * J.s_c] : 0.f;
+  }
+}
+
 __global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gpre,
                                long long n, int act, float slope) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,6 +401,28 @@ extern "C" int ali_pack_weights(const float* src, float* dst, int32_t N, int32_t
   hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(kEwBlock), 0, ST(stream), src, dst, N, T, C, Cpad,
                      (long long)s_n, (long long)s_tap, (long long)s_c);
   return check_launch("pack_weights_kernel");
+}
+
+extern "C" int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, float* const* dst, const int32_t* dims,
+                                      const int64_t* strides, ali_stream_t stream) {
+  if (n_jobs < 1 || n_jobs > 40 || !src || !dst || !dims || !strides) { set_error("ali_pack_weights_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+  PackJobs jobs;
+  int blk = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    PackJob& J = jobs.j[i];
+    J.src = src[i]; J.dst = dst[i];
+    J.N = dims[4 * i]; J.T = dims[4 * i + 1]; J.C = dims[4 * i + 2]; J.Cpad = dims[4 * i + 3];
+    J.s_n = strides[3 * i]; J.s_tap = strides[3 * i + 1]; J.s_c = strides[3 * i + 2];
+    if (!J.src || !J.dst || J.N <= 0 || J.T <= 0 || J.C <= 0 || J.Cpad < J.C) { set_error("ali_pack_weights_multi: bad job %d", i); return ALI_ERR_BAD_ARG; }
+    J.blk0 = blk;
+    long long nb = ((long long)J.N * J.T * J.Cpad + kEwBlock * 4 - 1) / (kEwBlock * 4);
+    if (nb > 256) nb = 256;
+    if (nb < 1) nb = 1;
+    blk += (int)nb;
+  }
+  jobs.n = n_jobs;
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(blk), dim3(kEwBlock), 0, ST(stream), jobs);
+  return check_launch("pack_weights_multi_kernel");
 }
 
 extern "C" int ali_act_bwd(const float* gy, const float* y, float* gpre, int64_t n, int32_t act, float slope,

@@ -562,7 +562,7 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   for (int i = 0; i < d.nphase; ++i) {
     // small maps with a large batch: order rows (pixel, image) so that every M-tile sees one pixel position
     // and the taps falling outside the input (padding, 1x1 -> 3x3 transposed convs) are skipped tile-wide
-    d.ph[i].pixmajor = (d.ph[i].Hq * d.ph[i].Wq <= 64 && d.B >= 32) ? 1 : 0;
+    d.ph[i].pixmajor = (d.ph[i].Hq * d.ph[i].Wq <= 1024 && d.B >= 64) ? 1 : 0;
     d.ph[i].tile0 = tiles;
     tiles += (d.ph[i].M + tc.bm - 1) / tc.bm;
   }

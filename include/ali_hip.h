@@ -111,6 +111,11 @@ int ali_tconv1_wgrad(const float* big, const float* small, int32_t sstride, int3
 int ali_pack_weights(const float* src, float* dst, int32_t N, int32_t T, int32_t C, int32_t Cpad,
                      int64_t s_n, int64_t s_tap, int64_t s_c, ali_stream_t stream);
 
+/* the same for up to 40 parameters in one launch (all packs of a parameter group after its Adam step):
+ * dims[4*i..] = {N, T, C, Cpad}, strides[3*i..] = {s_n, s_tap, s_c} of job i (host arrays). */
+int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, float* const* dst, const int32_t* dims,
+                           const int64_t* strides, ali_stream_t stream);
+
 /* ---- pointwise / reduction kernels (HBM bound) --------------------------- */
 /* gpre = gy * act'(y)  (backward of nn.LeakyReLU / nn.Tanh, mnist.py:32-73) */
 int ali_act_bwd(const float* gy, const float* y, float* gpre, int64_t n, int32_t act, float slope,
