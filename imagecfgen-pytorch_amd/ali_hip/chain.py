@@ -309,6 +309,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             (prev.unflat[0] if prev.unflat else prev.mod.out_features) if prev is not None else c_log_in)
         if need_params:
             # ---- parameter gradients of this stage
+            fused_db = None
             if m.bias is not None:
                 if st.kind == "linear" and st.unflat:
                     Cc, hh, ww = st.unflat
@@ -316,6 +317,12 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                     if id(m.bias) in grad_dst:
                         db = grad_dst[id(m.bias)].copy_(db)
                     grads[id(m.bias)] = db
+                elif st.kind == "conv" and not (i == 0 and _first_conv_direct(st, c_in_log)):
+                    # Conv2d: the bias gradient is the column sum of the dense wgrad operand -> fused into that launch
+                    fused_db = grad_dst.get(id(m.bias))
+                    if fused_db is None:
+                        fused_db = torch.empty(K, dtype=torch.float32, device=gy.device)
+                    grads[id(m.bias)] = fused_db
                 else:
                     grads[id(m.bias)] = ops.colsum(rows_out, K, K, g_pre, out=grad_dst.get(id(m.bias)))
             dw = grad_dst[id(m.weight)] if id(m.weight) in grad_dst else torch.empty_like(m.weight)
@@ -326,7 +333,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                                  m.kernel_size[0], m.kernel_size[1], m.padding[0])
             elif st.kind == "conv":
                 T = m.kernel_size[0] * m.kernel_size[1]
-                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1)
+                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1, db=fused_db)
             elif _is_tconv1(st, Cp):
                 T = m.kernel_size[0] * m.kernel_size[1]
                 ops.tconv1_wgrad(sv.t, g_pre, 1, 1, dw, T, 1, 0, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1],

@@ -149,13 +149,14 @@ def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
     return dx
 
 
-def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap):
+def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap, db=None):
+    """``db`` (optional, [cd_log]): also produce the column sums of ``dy`` (Conv2d bias gradient) in the same launch."""
     lib = _lib.load()
     ws = workspace(x.device)
     with _Timed("wgrad", g):
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
-                                           s_dc, s_gc, s_tap, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-                   "ali_conv_bwd_weight")
+                                           s_dc, s_gc, s_tap, _opt(db, "db"), c_void_p(ws.data_ptr()), ws.numel(),
+                                           _stream()), "ali_conv_bwd_weight")
     return dst
 
 

@@ -29,6 +29,8 @@ struct WDesc {
   long long s_dc, s_gc, s_tap;
   int Mtot;            // R*S*Cg
   int npix, pix_per_split, splitk;
+  float* db;          // optional: db[dc] = sum_pix dy[pix][dc] (bias gradient), fused into the m-tile-0 blocks
+  float* dbws;        // [splitk][Cd] slabs when splitk > 1
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VECA, bool VECB>
@@ -253,6 +255,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   __syncthreads();
 
   f32x4 ra[AP], rb[BP];
+  const bool do_db = d.db != nullptr && blockIdx.x == 0;
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
   auto load_a = [&](int pix0, int i) {
     const int pix = pix0 + arow0 + i * AROWS;
     unsigned off = OOB;
@@ -275,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf][(arow0 + i * AROWS) * LDA + a4 * 4]) = ra[i];
 #pragma unroll
-    for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(brow0 + j * BROWS) * LDB + b4 * 4]) = rb[j];
+    for (int j = 0; j < BP; ++j) {
+      *reinterpret_cast<f32x4*>(&Bs[buf][(brow0 + j * BROWS) * LDB + b4 * 4]) = rb[j];
+      if (do_db) dbacc += rb[j];
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -341,7 +348,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
             for (int x = 0; x < NL; ++x) {
               if ((x * Q) / NL != sw) continue;
               if (x < AP) *reinterpret_cast<f32x4*>(&As[buf ^ 1][(arow0 + x * AROWS) * LDA + a4 * 4]) = ra[x];
-              else *reinterpret_cast<f32x4*>(&Bs[buf ^ 1][(brow0 + (x - AP) * BROWS) * LDB + b4 * 4]) = rb[x - AP];
+              else {
+                *reinterpret_cast<f32x4*>(&Bs[buf ^ 1][(brow0 + (x - AP) * BROWS) * LDB + b4 * 4]) = rb[x - AP];
+                if (do_db) dbacc += rb[x - AP];
+              }
             }
           }
         }
@@ -353,6 +363,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   }
 
   const bool partial = d.splitk > 1;
+  if (do_db) {   // fold the per-thread column sums over the BROWS row lanes (fixed order), then one store per column
+    __syncthreads();
+    float* red = &As[0][0];                       // BROWS x BN floats <= tile size
+    *reinterpret_cast<f32x4*>(&red[brow0 * BN + b4 * 4]) = dbacc;
+    __syncthreads();
+    if (t < BN) {
+      float sum = 0.f;
+      for (int r = 0; r < BROWS; ++r) sum += red[r * BN + t];
+      const int n = n0 + t;
+      if (n < d.Cd_log) {
+        if (partial) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
+        else d.db[n] = sum;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 32 + (lane & 31);
@@ -378,10 +403,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 // dst[dc*s_dc + gc*s_gc + tap*s_tap] = sum_s ws[s][tap*Cg+gc][dc]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log,
                                     int Cd_log, long long s_dc, long long s_gc, long long s_tap,
-                                    float* __restrict__ dst) {
+                                    float* __restrict__ dst, const float* __restrict__ dbws, float* __restrict__ db) {
   const long long total = (long long)Mtot * Cd;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
+  if (db && i < Cd_log) {
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += dbws[(long long)s * Cd + i];
+    db[i] = v;
+  }
   for (; i < total; i += step) {
     const int dc = (int)(i % Cd);
     const int m = (int)(i / Cd);
@@ -398,7 +428,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mto
 using namespace ali;
 
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
-                                   int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, void* ws,
+                                   int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db, void* ws,
                                    size_t ws_bytes, ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
@@ -435,12 +465,14 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     S = (int)((4 * kNumCU + blocks - 1) / blocks);
     if (S > nkt / 2) S = nkt / 2;
     if (S > 128) S = 128;
-    while (S > 1 && (size_t)S * d.Mtot * g->K * sizeof(float) > ws_bytes) --S;
+    while (S > 1 && (size_t)S * ((size_t)d.Mtot + 1) * g->K * sizeof(float) > ws_bytes) --S;
     if (S < 1) S = 1;
   }
   d.splitk = S;
   int per = (nkt + S - 1) / S;
   d.pix_per_split = per * wbk;
+  d.db = fast ? db : nullptr;
+  d.dbws = d.ws + (size_t)S * d.Mtot * g->K;
   dim3 grid(tiles_m, tiles_n, S), block(256);
   if (fast) {
     const unsigned xb = (unsigned)(x_elems * 4), yb = (unsigned)(dy_elems * 4);
@@ -468,8 +500,10 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
-                       Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst);
+                       Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db);
     rc = check_launch("wgrad_reduce_kernel");
   }
+  if (!rc && db && !fast)   // generic path: bias gradient by the stand-alone column-sum kernels
+    rc = ali_colsum(dy, (int64_t)d.npix, Cd_log, g->K, db, ws, ws_bytes, stream_);
   return rc;
 }

@@ -84,6 +84,7 @@ int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w_cxk,
                       const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
 int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst,
                         int32_t Cg_log, int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap,
+                        float* db /* optional: db[dc] = sum over pixels of dy (Conv2d bias gradient) */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
 
 /* ---- direct kernels for the one-channel ends of the stacks (VALU + LDS, HBM bound) ----------

@@ -88,8 +88,10 @@ def test_conv2d_fwd_bwd(B, C, H, K, R, stride, pad):
     if cpad != C:
         assert dx[..., C:].abs().max().item() == 0.0
     dw = torch.empty(K, C, R, R, device="cuda")
-    ops.conv_bwd_weight(geom, xh, gpre, dw, C, K, C * R * R, R * R, 1)
+    db2 = torch.empty(K, device="cuda")
+    ops.conv_bwd_weight(geom, xh, gpre, dw, C, K, C * R * R, R * R, 1, db=db2)
     close(dw, wr.grad, what="wgrad")
+    close(db2, br.grad, what="db fused into wgrad")
 
 
 CONVT_CASES = [
