@@ -39,6 +39,28 @@ def synth_batch(bs, device, seed):
     return images.to(device), {k: v.to(device) for k, v in c.items()}, z.to(device)
 
 
+SPECT = {   # image side, categorical attrs, continuous attr, module  (reference audio_mnist.py:22-30, whalecalls.py:14-19,
+    # esrf_acoustic.py:17-20); default per-GPU batch of BASELINE.json configs 3-5
+    "audio": (128, {"country_of_origin": 13, "native_speaker": 2, "accent": 15, "digit": 10, "age": 5, "gender": 2}, None,
+              "image_scms.audio_mnist", 256),
+    "whale": (256, {"call_type": 3}, None, "image_scms.whalecalls", 128),
+    "esrf": (512, {"has_boat": 2}, "closest_boat", "image_scms.esrf_acoustic", 64),
+}
+
+
+def synth_spect_batch(workload, bs, device, seed):
+    """images ~ clip(N(0,1),-3,3)/3 (what spect_to_img yields, audio_mnist.py:361-363), uniform one-hot attributes."""
+    import torch
+    side, cats, cont, _, _ = SPECT[workload]
+    g = torch.Generator().manual_seed(seed)
+    images = torch.clip(torch.randn(bs, 1, side, side, generator=g), -3, 3) / 3
+    c = {k: torch.nn.functional.one_hot(torch.randint(0, v, (bs,), generator=g), v).float() for k, v in cats.items()}
+    if cont:
+        c[cont] = torch.rand(bs, 1, generator=g) * 2 - 1
+    z = torch.randn(bs, 512, 1, 1, generator=g)
+    return images.to(device), {k: v.to(device) for k, v in c.items()}, z.to(device)
+
+
 def cpu_baseline(bs, budget_s=25.0):
     """The CPU oracle (torch-CPU restatement of the reference iteration, bit-identical to the reference in the
     build container) timed on this host: 1 warm-up + as many iterations as fit in the budget (>= 2)."""
@@ -78,7 +100,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BS_PER_GPU)
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE.json config's)")
+    ap.add_argument("--workload", default="mnist", choices=["mnist", "audio", "whale", "esrf"],
+                    help="mnist = BASELINE.json configs[1] (the headline metric); the others are configs[2..4]")
     ap.add_argument("--mode", default="stepper", choices=["stepper", "autograd"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,24 +130,32 @@ def main():
     ali_hip.load()
 
     torch.manual_seed(1)                       # identical replicas; per-rank data / z / dropout streams
+    if args.workload != "mnist":
+        import importlib
+        pm = importlib.import_module(SPECT[args.workload][3])
     E, G, D = pm.Encoder(), pm.Generator(), pm.Discriminator()
     for m in (E, G, D):
         m.apply(pm.init_weights)
         m.to(dev).train()
     ali_hip.manual_seed(1234 + rank)
-    bs = args.batch
-    batches = [synth_batch(bs, dev, 100 + rank * 17 + i) for i in range(4)]
+    bs = args.batch or (BS_PER_GPU if args.workload == "mnist" else SPECT[args.workload][4])
+    if args.workload == "mnist":
+        batches = [synth_batch(bs, dev, 100 + rank * 17 + i) for i in range(4)]
+    else:
+        ops.set_workspace_bytes(2 << 30)
+        batches = [synth_spect_batch(args.workload, bs, dev, 100 + rank * 17 + i) for i in range(2)]
+    betas = (0.5, 0.999) if args.workload == "mnist" else (0.5, 0.9)
 
     if args.mode == "stepper":
-        stepper = AliStepper(E, G, D, process_group=pg, capture=not args.no_graph)
+        stepper = AliStepper(E, G, D, betas=betas, process_group=pg, capture=not args.no_graph)
 
         def one(i):
             images, c, z = batches[i % len(batches)]
             return stepper.step(images, c, z)
     else:
         assert world == 1, "autograd mode is single-GPU (reference schedule through torch.autograd)"
-        oe = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=1e-4, betas=(0.5, 0.999))
-        od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        oe = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=1e-4, betas=betas)
+        od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=betas)
 
         def one(i):
             images, c, z = batches[i % len(batches)]
@@ -185,13 +217,18 @@ def main():
                     "launches_per_step": f["launches"], "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2),
                     "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()}}
+        names = {"mnist": "image_scms/mnist.py ALI iteration (EG step + 2 D steps + diagnostics), MorphoMNIST 28x28x1",
+                 "audio": "image_scms/audio_mnist.py ALI iteration, AudioMNIST log-spectrogram 128x128x1",
+                 "whale": "image_scms/whalecalls.py BiGAN iteration, whale-call spectrogram 256x256x1",
+                 "esrf": "image_scms/esrf_acoustic.py ALI iteration, ESRF spectrogram 512x512x1"}
         out = {
-            "metric": "ALI training images/sec (E+G+D step), MorphoMNIST bs=512/GPU", "value": round(value, 1),
+            "metric": "ALI training images/sec (E+G+D step), MorphoMNIST bs=512/GPU" if args.workload == "mnist" else
+                      f"ALI training images/sec (E+G+D step), {args.workload} bs={bs}/GPU",
+            "value": round(value, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "image_scms/mnist.py ALI iteration (EG step + 2 D steps + diagnostics), "
-                                   f"MorphoMNIST 28x28x1 synthetic, bs={bs}/GPU, fp32 MFMA, mode={args.mode}"
+            "config": {"workload": f"{names[args.workload]} synthetic, bs={bs}/GPU, fp32 MFMA, mode={args.mode}"
                                    f"{'' if args.no_graph or world > 1 or args.mode != 'stepper' else '+hipgraph'}",
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "roofline": roof,
@@ -200,7 +237,9 @@ def main():
                               "alg_bytes_per_img": ALG_BYTES_PER_IMG, "alg_flop_per_img": ALG_FLOP_PER_IMG},
             "losses_last_step": losses,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.workload != "mnist":
+            out["step_roofline"] = None          # SURVEY 8(d) per-image figures of the other configs: see DESIGN.md
+        if world == 1 and not args.no_cpu_baseline and args.workload == "mnist":
             out["cpu_baseline"] = cpu_baseline(bs)
         else:
             out["cpu_baseline"] = None
