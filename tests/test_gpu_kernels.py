@@ -295,3 +295,60 @@ def test_direct_one_channel_kernels(B, K, P, R, pad):
     ref0 = torch.empty(K, 1, R, R, device="cuda")
     ops.tconv1_wgrad(xin, g4[..., 0].contiguous(), 1, 1, ref0, T, 1, 0, B, P, P, K, R, R, pad)
     close(dw2[:, 0], ref0[:, 0], rtol=1e-6, what="multi-channel small, plane 0")
+
+
+FULL_SIZE = [  # the MorphoMNIST layer shapes at the bench batch (BASELINE.json configs[1], bs=512/GPU)
+    ("conv", 512, 64, 14, 128, 4, 2, 1), ("conv", 512, 128, 7, 256, 4, 2, 1), ("conv", 512, 32, 24, 64, 4, 2, 0),
+    ("conv", 512, 64, 11, 128, 4, 1, 0), ("conv", 512, 1024, 1, 1024, 1, 1, 0), ("conv", 512, 256, 3, 512, 3, 1, 0),
+    ("convT", 512, 512, 3, 256, 3, 2, 0), ("convT", 512, 128, 13, 64, 3, 2, 1), ("convT", 512, 800, 1, 512, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", FULL_SIZE)
+def test_full_size_adjoint_identities(kind, B, C, H, K, R, stride, pad):
+    """Size-independent properties at the bench batch (too big for the CPU oracle): the three kernels of a layer are
+    mutually adjoint,  <dy, conv(x, w)> = <dgrad(dy, w), x> = <wgrad(x, dy), w>,  and conv is linear in x."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    T = R * R
+    if kind == "conv":
+        P = (H + 2 * pad - R) // stride + 1
+        xs, ys, wshape = (B, H, H, C), (B, P, P, K), (K, C, R, R)
+        geom = ops.geom(B, H, H, C, P, P, K, R, R, stride, pad)
+    else:   # ConvTranspose2d(C -> K): described by the conv it is the data gradient of (x := its output)
+        P = (H - 1) * stride - 2 * pad + R
+        xs, ys, wshape = (B, H, H, C), (B, P, P, K), (C, K, R, R)
+        geom = ops.geom(B, P, P, K, H, H, C, R, R, stride, pad)
+    x = torch.randn(xs, device="cuda", generator=g)
+    x2 = torch.randn(xs, device="cuda", generator=g)
+    dy = torch.randn(ys, device="cuda", generator=g)
+    w = torch.randn(wshape, device="cuda", generator=g) / (C * T) ** 0.5
+    y, y2, y3 = (torch.empty(ys, device="cuda") for _ in range(3))
+    dx = torch.empty(xs, device="cuda")
+    dw = torch.empty(wshape, device="cuda")
+    if kind == "conv":
+        wf = torch.empty(K, T, C, device="cuda")
+        ops.pack_weights(w, wf, K, T, C, C, C * T, 1, T)
+        wd = torch.empty(C, T, K, device="cuda")
+        ops.pack_weights(w, wd, C, T, K, K, T, 1, C * T)
+        fwd = lambda inp, out: ops.conv_fwd(geom, inp, wf, out, ops.epilogue())            # noqa: E731
+        ops.conv_bwd_data(geom, dy, wd, dx, ops.epilogue())
+        ops.conv_bwd_weight(geom, x, dy, dw, C, K, C * T, T, 1)
+    else:
+        wf = torch.empty(K, T, C, device="cuda")
+        ops.pack_weights(w, wf, K, T, C, C, T, 1, K * T)
+        wd = torch.empty(C, T, K, device="cuda")
+        ops.pack_weights(w, wd, C, T, K, K, K * T, 1, T)
+        fwd = lambda inp, out: ops.conv_bwd_data(geom, inp, wf, out, ops.epilogue())       # noqa: E731
+        ops.conv_fwd(geom, dy, wd, dx, ops.epilogue())
+        ops.conv_bwd_weight(geom, dy, x, dw, K, C, K * T, T, 1)
+    fwd(x, y)
+    fwd(x2, y2)
+    fwd(2.5 * x - 0.75 * x2, y3)
+    lin = (y3 - (2.5 * y - 0.75 * y2)).abs().max().item() / (y.abs().max().item() + 1e-30)
+    assert lin < 1e-5, f"linearity {lin:.2e}"
+    a = (dy.double() * y.double()).sum().item()
+    b = (dx.double() * x.double()).sum().item()
+    c = (dw.double() * w.double()).sum().item()
+    scale = (dy.double().norm() * y.double().norm()).item()
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
