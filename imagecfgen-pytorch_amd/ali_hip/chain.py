@@ -12,6 +12,7 @@ data-gradient GEMM, BatchNorm backward is fused with the LeakyReLU derivative.
 The ``nn`` modules only own the parameters (reference layouts, reference
 ``state_dict`` keys); their own ``forward`` is never called on CUDA tensors.
 """
+import weakref
 from typing import List, Optional
 
 import torch
@@ -67,7 +68,7 @@ class PackCache:
 
 class ChainPlan:
     def __init__(self, seq: nn.Sequential):
-        self.seq = seq
+        self.seq = weakref.ref(seq)          # the plan lives in a WeakKeyDictionary keyed by seq: no strong cycle
         self.stages: List[Stage] = []
         self.cache = PackCache()
         pre = []
@@ -423,11 +424,15 @@ class ChainFn(torch.autograd.Function):
         return (None, None, None, gx) + pg
 
 
+_PLANS = weakref.WeakKeyDictionary()   # nn.Sequential -> ChainPlan; kept OUT of the module so that the reference's
+#                                        checkpoint style torch.save({'E': E, ...}) (train_mnist_image_scm.py:61-67) still pickles
+
+
 def get_plan(seq: nn.Sequential) -> ChainPlan:
-    plan = seq.__dict__.get("_ali_plan")
-    if plan is None or plan.seq is not seq:
+    plan = _PLANS.get(seq)
+    if plan is None or plan.seq() is not seq:
         plan = ChainPlan(seq)
-        seq.__dict__["_ali_plan"] = plan
+        _PLANS[seq] = plan
     return plan
 
 

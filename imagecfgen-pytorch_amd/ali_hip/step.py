@@ -469,3 +469,67 @@ class AliStepper:
             st["c"][k].copy_(v)
         graph.replay()
         return res
+
+
+class FinetuneStepper:
+    """Encoder fine-tuning against a frozen Generator, hand scheduled (reference
+    finetune_mnist_bigan.py:64-85, finetune_audio_mnist_bigan.py, finetune_whale_bigan.py with ``--metric mse``):
+
+        codes = E(x, a); xr = G(codes, a); loss = mean((x - xr)^2) + mean(codes^2); Adam(E).step()
+
+    E runs forward + full backward, G forward + data gradient only (its weight gradients are never used by the
+    reference's optimiser), the two scalar losses and their gradients are O(B*H*W) torch ops.
+    ``step`` returns {"rec": mse, "latent": mean(codes^2)} as 0-d device tensors (no host sync)."""
+
+    def __init__(self, E, G, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, family=None):
+        self.E, self.G = E, G
+        self.family = family or (SpectFamily(E, G, E) if hasattr(E, "cat_keys") else _mnist_family_eg(E, G))
+        self.pE, self.pG = get_plan(E.layers), get_plan(G.layers)
+        self.opt_e = FlatGroup(list(E.parameters()), lr, betas, eps)
+        self.pE.cache.store.clear()
+        self.pE.cache.static = True
+
+    @torch.no_grad()
+    def step(self, x, a):
+        fam = self.family
+        B = x.shape[0]
+        H, W = fam.hw
+        idx, cont, onehots = fam.conditioning(a)
+        n_log = 1 + len(fam.e_tables) + (0 if cont is None else cont.shape[1])
+        x0 = ops.assemble_planes(x.reshape(B, H, W).float().contiguous(), idx, [t.detach() for t in fam.e_tables],
+                                 cont, B, H, W, (n_log + 3) // 4 * 4)
+        codes, sE = chain_forward(self.pE, x0, self.E.training, n_log, True)
+        zin = codes.reshape(B, -1)
+        feats = [zin] + [oh.matmul(t.detach()) for oh, t in zip(onehots, fam.g_tables)]
+        if cont is not None:
+            feats.append(cont)
+        g_log = sum(f.shape[1] for f in feats)
+        pad = (-g_log) % 32
+        if pad:
+            feats.append(torch.zeros(B, pad, device=x.device))
+        gin = torch.cat(feats, dim=1).reshape(B, 1, 1, -1)
+        xr, sG = chain_forward(self.pG, gin, self.G.training, g_log, True)
+        diff = xr.reshape(B, -1) - x.reshape(B, -1).float()
+        rec = diff.square().mean()
+        latent = zin.square().mean()
+        g_xr = (diff * (2.0 / diff.numel())).reshape(xr.shape).contiguous()
+        g_gin, _ = chain_backward(self.pG, sG, g_xr, g_log, True, need_params=False)
+        g_codes = (g_gin.reshape(B, -1)[:, :zin.shape[1]] + zin * (2.0 / zin.numel())).contiguous()
+        dst = self.opt_e.grad_views
+        g_x0, _ = chain_backward(self.pE, sE, g_codes.reshape(codes.shape), n_log, True, True, dst)
+        from .planes import plane_to_table_grad
+        for j, t in enumerate(fam.e_tables):
+            plane = x0[..., 1 + j].reshape(B, H * W)
+            gp = g_x0[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)
+            dst[id(t)].copy_(plane_to_table_grad(gp, idx[:, j], t.shape[0], H, W))
+        self.opt_e.adam()
+        self.pE.cache.refresh()
+        return {"rec": rec, "latent": latent}
+
+
+def _mnist_family_eg(E, G):
+    fam = MnistFamily.__new__(MnistFamily)
+    fam.e_tables = [E.digit_embedding[0].weight]
+    fam.d_tables = []
+    fam.g_tables = [G.digit_embedding.weight]
+    return fam

@@ -488,3 +488,46 @@ def test_segmented_graph_replay_equals_eager():
     assert torch.equal(eager.opt_d.flat, seg.opt_d.flat) and torch.equal(eager.opt_eg.flat, seg.opt_eg.flat)
     for (k, v1), (_, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
         assert torch.equal(v1, v2), k
+
+
+def test_finetune_stepper_matches_reference_trace(golden_dir):
+    """FinetuneStepper (E fwd+bwd, G fwd + dgrad only, Adam(E)) reproduces finetune_mnist_bigan.py:64-85 (mse)."""
+    import os
+    import image_scms.mnist as pm
+    from ali_hip.step import FinetuneStepper
+    g = np.load(os.path.join(golden_dir, "callers_mnist.npz"), allow_pickle=False)
+    torch.manual_seed(31)
+    np.random.seed(31)
+    E, G = pm.Encoder(), pm.Generator()
+    E.apply(pm.init_weights), G.apply(pm.init_weights)
+    orc.rescale_for_test_(E, 0.01, bias_seed=7), orc.rescale_for_test_(G, 0.01, bias_seed=8)
+    E, G = E.cuda(), G.cuda()
+    xs, a = orc.synth_morphomnist(8, seed=4)
+    stats = {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"}
+    x, c = orc.mnist_scale_batch(xs, a, stats)
+    E.train(), G.eval()
+    ft = FinetuneStepper(E, G, lr=1e-4)
+    out = [ft.step(x.cuda(), to_dev(c)) for _ in range(2)]
+    np.testing.assert_allclose([o["rec"].item() for o in out], g["rec"], rtol=1e-4)
+    np.testing.assert_allclose([o["latent"].item() for o in out], g["lat"], rtol=1e-4)
+
+
+def test_pickled_module_checkpoint_roundtrip(tmp_path):
+    """The reference saves whole modules (train_mnist_image_scm.py:61-67) and its callers torch.load them
+    (finetune_mnist_bigan.py:60-62): modules that have already run on the HIP path must still pickle."""
+    import image_scms.mnist as pm
+    from ali_hip.step import AliStepper
+    (_, _, _), (E, G, D), images, c, z = paired_models("mnist")
+    ex = E(images.cuda(), to_dev(c))                      # builds the kernel plans / packed weights
+    stepper = AliStepper(E, G, D)                         # re-points parameters into the flat buffers
+    stepper.step(images.cuda(), to_dev(c), z.cuda())
+    path = tmp_path / "ckpt.tar"
+    torch.save({"E": E, "G": G, "D": D, "E_state_dict": E.state_dict()}, path)
+    ck = torch.load(path, map_location="cuda", weights_only=False)
+    E2, G2 = ck["E"], ck["G"]
+    E.eval(), G.eval(), E2.eval(), G2.eval()
+    with torch.no_grad():
+        assert torch.equal(G2(E2(images.cuda(), to_dev(c)), to_dev(c)), G(E(images.cuda(), to_dev(c)), to_dev(c)))
+    E3 = pm.Encoder()
+    E3.load_state_dict(ck["E_state_dict"])
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(E3.state_dict().values(), E.state_dict().values()))
