@@ -219,12 +219,37 @@ def _first_conv_direct(st: Stage, c_in_log: int) -> bool:
             and m.kernel_size[0] <= 5)
 
 
-def _pad_mask(mask, cpad):
-    if mask.shape[1] == cpad:
-        return mask
-    out = torch.ones(mask.shape[0], cpad, device=mask.device)
-    out[:, :mask.shape[1]] = mask
-    return out
+_NBT = {"pending": None}
+
+
+def _count_batch(bn):
+    """num_batches_tracked += 1 (nn.BatchNorm2d training forward).  Inside a stepper iteration the increments are
+    collected and applied by one multi-tensor launch (``flush_batch_counts``) instead of one launch per forward."""
+    pend = _NBT["pending"]
+    if pend is None:
+        bn.num_batches_tracked += 1
+    else:
+        ent = pend.setdefault(id(bn), [bn.num_batches_tracked, 0])
+        ent[1] += 1
+
+
+def defer_batch_counts():
+    _NBT["pending"] = {}
+
+
+def drop_pending_batch_counts():
+    if _NBT["pending"] is not None:
+        _NBT["pending"] = {}
+
+
+def abort_batch_counts():
+    _NBT["pending"] = None
+
+
+def flush_batch_counts():
+    pend, _NBT["pending"] = _NBT["pending"], None
+    if pend:
+        torch._foreach_add_([e[0] for e in pend.values()], [e[1] for e in pend.values()])
 
 
 class _Saved:
@@ -236,15 +261,19 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
     saved = []
     cur = x
     c_log = c_log_in
-    for st in plan.stages:
+    folded = None        # mask of the coming stage, already applied by the previous stage's GEMM epilogue
+    for si, st in enumerate(plan.stages):
         B, H, W, Cp = cur.shape
         rows = H * W
         kinds = [p[0] for p in st.pre]
         mask = None
         bn = None
+        mask_applied = folded is not None
+        if mask_applied:
+            mask, folded = folded, None
         for kind, arg in st.pre:
-            if kind == "drop" and training:
-                mask = _pad_mask(_dropout.next_mask(B, c_log, arg, cur.device), Cp)
+            if kind == "drop" and training and not mask_applied:
+                mask = _dropout.next_mask(B, c_log, arg, cur.device, Cp)
             elif kind == "bn":
                 bn = arg
         sv = _Saved()
@@ -259,15 +288,22 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             st4 = ops.bn_stats(cur, mask_in, B, rows, Cp, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch)
             if use_batch and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+                _count_batch(bn)
             t = ops.bn_apply(cur, st4, mask_in, mask_post, B, rows, Cp)
             sv.bn_stats = st4
-        elif mask is not None:
+        elif mask is not None and not mask_applied:
             t = ops.rowmask_mul(cur, mask, B, rows, Cp)
         out_shape = _out_shape(st, B, H, W, Cp)
         g = _geom(st, (B, H, W, Cp), out_shape)
         y = torch.empty(out_shape, dtype=torch.float32, device=cur.device)
-        ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope)
+        # A lone Dropout2d in front of the next stage multiplies this stage's output by a per-(sample, channel)
+        # mask: the GEMM epilogue does it (act(.)*mask), so y is stored masked.  LeakyReLU'(y) only needs the sign
+        # of y, which the kept entries preserve and the dropped ones do not need (their gradient is masked to 0).
+        nxt = plan.stages[si + 1] if si + 1 < len(plan.stages) else None
+        if (training and nxt is not None and [p[0] for p in nxt.pre] == ["drop"] and st.act in (ACT_NONE, ACT_LEAKY)
+                and st.kind in ("conv", "convT") and not _is_tconv1(st, Cp)):
+            folded = _dropout.next_mask(B, out_shape[3], nxt.pre[0][1], cur.device, out_shape[3])
+        ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope, mask=folded)
         if _is_tconv1(st, Cp):
             m = st.mod
             ops.tconv1_fwd(t, plan.packed(st, "fwd", Cp), plan.packed_bias(st), y, B, H, W, Cp, m.kernel_size[0],
@@ -389,10 +425,10 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             slope = pslope if pact == ACT_LEAKY else -1.0
             want = (i > 0) or need_gx
             dgam, dbet, gprev = ops.bn_bwd(sv.x_in, gt, mask_in, mask_pre, sv.bn_stats, bn.weight.detach(), B, H * W,
-                                           Cp, use_batch, slope, want_gx=want)
+                                           Cp, use_batch, slope, want_gx=want,
+                                           out_dgamma=grad_dst.get(id(bn.weight)) if need_params else None,
+                                           out_dbeta=grad_dst.get(id(bn.bias)) if need_params else None)
             if need_params:
-                if id(bn.weight) in grad_dst:
-                    dgam, dbet = grad_dst[id(bn.weight)].copy_(dgam), grad_dst[id(bn.bias)].copy_(dbet)
                 grads[id(bn.weight)] = dgam
                 grads[id(bn.bias)] = dbet
             if pact == ACT_TANH and gprev is not None:

@@ -48,7 +48,8 @@ def begin_iteration(dev_counter, owner=None):
         _state["record"] = {"owner": owner, "req": []}
         return
     _state["record"] = None
-    ops.dropout_mask_multi(_state["seed"], dev_counter, plan["ends"], plan["ps"], plan["buf"])
+    ops.dropout_mask_multi(_state["seed"], dev_counter, plan["ends"], plan["ps"], plan["clog"], plan["cpad"],
+                           plan["buf"])
 
 
 def end_iteration():
@@ -56,13 +57,13 @@ def end_iteration():
     _state["record"] = None
     if rec is None or not rec["req"] or len(rec["req"]) > 64:
         return
-    ends, ps, off = [], [], 0
-    for B, C, p in rec["req"]:
-        off += B * C
+    ends, off = [], 0
+    for B, C, p, cpad in rec["req"]:
+        off += B * cpad
         ends.append(off)
-        ps.append(p)
     dev = rec["device"]
-    _state["plan"] = {"owner": rec["owner"], "req": rec["req"], "ends": ends, "ps": ps,
+    _state["plan"] = {"owner": rec["owner"], "req": rec["req"], "ends": ends, "ps": [r[2] for r in rec["req"]],
+                      "clog": [r[1] for r in rec["req"]], "cpad": [r[3] for r in rec["req"]],
                       "buf": torch.empty(off, dtype=torch.float32, device=dev)}
 
 
@@ -70,7 +71,17 @@ def masks_consumed() -> int:
     return _state["pos"]
 
 
-def next_mask(B: int, C: int, p: float, device) -> torch.Tensor:
+def _pad(mask, cpad):
+    if mask.shape[1] == cpad:
+        return mask
+    out = torch.ones(mask.shape[0], cpad, device=mask.device)
+    out[:, :mask.shape[1]] = mask
+    return out
+
+
+def next_mask(B: int, C: int, p: float, device, cpad=None) -> torch.Tensor:
+    """[B, cpad] mask of the next Dropout2d: columns < C are Bernoulli(1-p)/(1-p), channel-padding columns are 1."""
+    cpad = C if cpad is None else cpad
     inj = _state["inject"]
     if inj is not None:
         if _state["pos"] >= len(inj):
@@ -79,19 +90,19 @@ def next_mask(B: int, C: int, p: float, device) -> torch.Tensor:
         _state["pos"] += 1
         if tuple(m.shape) != (B, C):
             raise RuntimeError(f"injected mask shape {tuple(m.shape)} != {(B, C)}")
-        return m.to(device=device, dtype=torch.float32).contiguous()
+        return _pad(m.to(device=device, dtype=torch.float32).contiguous(), cpad)
     plan, rec = _state["plan"], _state["record"]
     if plan is not None and rec is None:
         i = _state["req"]
-        if i < len(plan["req"]) and plan["req"][i] == (B, C, p):
-            lo = plan["ends"][i] - B * C
+        if i < len(plan["req"]) and plan["req"][i] == (B, C, p, cpad):
+            lo = plan["ends"][i] - B * cpad
             _state["req"] = i + 1
-            _state["offset"] = plan["ends"][i]
-            return plan["buf"][lo:lo + B * C].view(B, C)
+            _state["offset"] += B * C
+            return plan["buf"][lo:lo + B * cpad].view(B, cpad)
         _state["plan"] = None          # request sequence changed: fall back to one launch per mask
     m = ops.dropout_mask(_state["seed"], _state["offset"], p, B, C, device, _state["dev_counter"])
     _state["offset"] += B * C
     if rec is not None:
-        rec["req"].append((B, C, p))
+        rec["req"].append((B, C, p, cpad))
         rec["device"] = device
-    return m
+    return _pad(m, cpad)

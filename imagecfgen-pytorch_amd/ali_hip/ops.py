@@ -277,14 +277,17 @@ def dropout_mask(seed, offset, p, B, C, device, dev_counter=None):
     return out
 
 
-def dropout_mask_multi(seed, dev_counter, seg_end, seg_p, out):
-    """one launch for all masks of an iteration; seg_end / seg_p are host lists."""
+def dropout_mask_multi(seed, dev_counter, seg_end, seg_p, seg_clog, seg_cpad, out):
+    """one launch for all masks of an iteration; seg_* are host lists (see ali_hip.h)."""
     lib = _lib.load()
     n = len(seg_end)
     ends = (ctypes.c_int64 * n)(*seg_end)
     ps = (ctypes.c_float * n)(*seg_p)
+    cl = (ctypes.c_int32 * n)(*seg_clog)
+    cp = (ctypes.c_int32 * n)(*seg_cpad)
     ctr = None if dev_counter is None else c_void_p(dev_counter.data_ptr())
-    _lib.check(lib.ali_dropout_mask_multi(seed, ctr, ends, ps, n, _chk(out), _stream()), "ali_dropout_mask_multi")
+    _lib.check(lib.ali_dropout_mask_multi(seed, ctr, ends, ps, cl, cp, n, _chk(out), _stream()),
+               "ali_dropout_mask_multi")
     return out
 
 
@@ -308,17 +311,20 @@ def bn_apply(x, st, mask_in, mask_post, B, rows_per_img, C, out=None):
     return out
 
 
-def bn_bwd(x, g, mask_in, mask_pre, st, gamma, B, rows_per_img, C, batch_stats, slope, want_gx=True):
-    """returns (dgamma, dbeta, gx)."""
+def bn_bwd(x, g, mask_in, mask_pre, st, gamma, B, rows_per_img, C, batch_stats, slope, want_gx=True, out_dgamma=None,
+           out_dbeta=None):
+    """returns (dgamma, dbeta, gx); out_dgamma / out_dbeta: optional contiguous [C] destinations."""
     lib = _lib.load()
     ws = workspace(x.device)
-    dg = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    if out_dgamma is None or out_dbeta is None:
+        dg = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        out_dgamma, out_dbeta = dg[0], dg[1]
     gx = torch.empty_like(x) if want_gx else None
     _lib.check(lib.ali_bn_bwd(_chk(x, "x"), _chk(g, "g"), _opt(mask_in), _opt(mask_pre), c_void_p(st[0].data_ptr()),
                               c_void_p(st[1].data_ptr()), _opt(gamma), B, rows_per_img, C, int(batch_stats),
-                              float(slope), c_void_p(dg[0].data_ptr()), c_void_p(dg[1].data_ptr()), _opt(gx),
+                              float(slope), _chk(out_dgamma, "dgamma"), _chk(out_dbeta, "dbeta"), _opt(gx),
                               c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_bn_bwd")
-    return dg[0], dg[1], gx
+    return out_dgamma, out_dbeta, gx
 
 
 def bce_logits(logit, target, gscale=1.0, want_grad=True):

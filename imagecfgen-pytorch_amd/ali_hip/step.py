@@ -27,6 +27,7 @@ import torch.nn as nn
 from . import dp
 from . import dropout as _dropout
 from . import ops
+from . import chain as _chain
 from .chain import chain_backward, chain_forward, get_plan
 
 
@@ -204,6 +205,7 @@ class AliStepper:
         B = images.shape[0]
         self.iter_t += 1
         _dropout.begin_iteration(self.iter_t, owner=self)
+        _chain.defer_batch_counts()
         idx, cont, onehots = self.family.conditioning(c)
         return {"images": images, "B": B, "idx": idx, "cont": cont, "onehots": onehots,
                 "zin": z.reshape(B, -1).float().contiguous(), "out": {}}
@@ -303,6 +305,7 @@ class AliStepper:
         cx["out"]["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
         cx["out"]["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
         _dropout.end_iteration()
+        _chain.flush_batch_counts()        # all BatchNorm num_batches_tracked increments of the iteration: one launch
         if self.world > 1 and average_bn:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
             dp.average_buffers_(self.bn_buffers, self.pg)
@@ -354,6 +357,7 @@ class AliStepper:
             sd = src.state_dict()
             for k, v in dst.state_dict().items():
                 v.copy_(sd[k])
+        _chain.drop_pending_batch_counts()      # the adopted num_batches_tracked already include them
         for group, opt, mods in ((self.opt_eg, opt_e, (E_src, G_src)), (self.opt_d, opt_d, (D_src,))):
             if opt is None:
                 continue
@@ -386,6 +390,12 @@ class AliStepper:
     @torch.no_grad()
     def step(self, images, c: Dict[str, torch.Tensor], z, do_eg=True, masks=None):
         """One iteration.  ``masks``: optional list of host-recorded Dropout2d masks (parity mode)."""
+        try:
+            return self._step(images, c, z, do_eg, masks)
+        finally:
+            _chain.abort_batch_counts()     # no-op after a completed iteration
+
+    def _step(self, images, c, z, do_eg, masks):
         if masks is not None:
             with _dropout.injected_masks(masks):
                 return self._iteration(images, c, z, do_eg)

@@ -129,21 +129,31 @@ __global__ void dropout_mask_kernel(uint64_t seed, uint64_t offset, const long l
   }
 }
 
-// all Dropout2d masks of one iteration in one launch: element i belongs to the segment whose end offset is the first
-// one > i and uses that segment's p; the draw for global index i is the same as dropout_mask_kernel(offset=0) gives
-struct MaskSegs { long long end[64]; float p[64]; int n; };
+// all Dropout2d masks of one iteration in one launch: blockIdx.y = segment (one [rows][cpad] mask), blockIdx.x strides
+// over its elements.  Column c < clog of row b takes the draw dropout_mask_kernel(offset = draw_start) gives index
+// b*clog + c (so the masks are bit-identical to one launch per mask); padding columns are 1.
+struct MaskSegs { long long out_end[64]; long long draw_start[64]; float p[64]; int clog[64]; int cpad[64]; int n; };
 __global__ void dropout_mask_multi_kernel(uint64_t seed, const long long* __restrict__ dev_counter, MaskSegs segs,
-                                          float* __restrict__ out, long long total) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long step = (long long)gridDim.x * blockDim.x;
+                                          float* __restrict__ out) {
+  const int s = blockIdx.y;
+  const long long lo = s ? segs.out_end[s - 1] : 0, n = segs.out_end[s] - lo;
+  const long long d0 = segs.draw_start[s];
+  const int clog = segs.clog[s], cpad = segs.cpad[s];
+  const float p = segs.p[s], keep = 1.f - p, inv = 1.f / (1.f - p);
   const uint64_t key = mix64(mix64(seed) ^ (dev_counter ? (uint64_t)dev_counter[0] * 0xD1B54A32D192ED03ull : 0ull));
-  for (; i < total; i += step) {
-    int s = 0;
-    while (s < segs.n - 1 && i >= segs.end[s]) ++s;
-    const float p = segs.p[s];
-    const uint64_t r = mix64(key ^ (uint64_t)i);
+  const long long step = (long long)gridDim.x * blockDim.x;
+  float* o = out + lo;
+  for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += step) {
+    long long di = j;
+    if (clog != cpad) {
+      const long long b = j / cpad;
+      const int c = (int)(j - b * cpad);
+      if (c >= clog) { o[j] = 1.f; continue; }
+      di = b * clog + c;
+    }
+    const uint64_t r = mix64(key ^ (uint64_t)(d0 + di));
     const float u = (float)(r >> 40) * (1.f / 16777216.f);
-    out[i] = u < 1.f - p ? 1.f / (1.f - p) : 0.f;
+    o[j] = u < keep ? inv : 0.f;
   }
 }
 
@@ -472,18 +482,34 @@ extern "C" int ali_dropout_mask(uint64_t seed, uint64_t offset, const int64_t* d
 }
 
 extern "C" int ali_dropout_mask_multi(uint64_t seed, const int64_t* dev_counter, const int64_t* seg_end,
-                                      const float* seg_p, int32_t n_seg, float* out, ali_stream_t stream) {
-  if (!seg_end || !seg_p || !out || n_seg < 1 || n_seg > 64) { set_error("ali_dropout_mask_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+                                      const float* seg_p, const int32_t* seg_clog, const int32_t* seg_cpad,
+                                      int32_t n_seg, float* out, ali_stream_t stream) {
+  if (!seg_end || !seg_p || !seg_clog || !seg_cpad || !out || n_seg < 1 || n_seg > 64) {
+    set_error("ali_dropout_mask_multi: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
   MaskSegs segs;
-  long long prev = 0;
+  long long prev = 0, draws = 0, longest = 0;
   for (int i = 0; i < n_seg; ++i) {
-    if (seg_end[i] <= prev || !(seg_p[i] >= 0.f && seg_p[i] < 1.f)) { set_error("ali_dropout_mask_multi: bad segment"); return ALI_ERR_BAD_ARG; }
-    segs.end[i] = prev = seg_end[i];
+    const long long len = seg_end[i] - prev;
+    if (len <= 0 || !(seg_p[i] >= 0.f && seg_p[i] < 1.f) || seg_clog[i] < 1 || seg_cpad[i] < seg_clog[i] ||
+        len % seg_cpad[i] != 0) {
+      set_error("ali_dropout_mask_multi: bad segment");
+      return ALI_ERR_BAD_ARG;
+    }
+    segs.out_end[i] = prev = seg_end[i];
+    segs.draw_start[i] = draws;
+    draws += len / seg_cpad[i] * seg_clog[i];
     segs.p[i] = seg_p[i];
+    segs.clog[i] = seg_clog[i];
+    segs.cpad[i] = seg_cpad[i];
+    if (len > longest) longest = len;
   }
   segs.n = n_seg;
-  hipLaunchKernelGGL(dropout_mask_multi_kernel, dim3(ew_grid(prev)), dim3(kEwBlock), 0, ST(stream), seed,
-                     reinterpret_cast<const long long*>(dev_counter), segs, out, prev);
+  int gx = (int)((longest + kEwBlock * 4 - 1) / (kEwBlock * 4));
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(dropout_mask_multi_kernel, dim3(gx, n_seg), dim3(kEwBlock), 0, ST(stream), seed,
+                     reinterpret_cast<const long long*>(dev_counter), segs, out);
   return check_launch("dropout_mask_multi_kernel");
 }
 

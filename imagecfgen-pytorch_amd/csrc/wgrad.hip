@@ -423,6 +423,58 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mto
   }
 }
 
+// Same reduction, laid out for the memory system: a block owns the [G gathered channels x all T taps] x [TD dense
+// channels] tile.  Slab rows are read as TD-float runs (float4 per lane), the S slabs are split over SGN thread groups
+// (fixed order inside a group, groups combined in order: deterministic), and the tile is written back through LDS so
+// that each dense channel stores one contiguous run of G*T floats of the reference weight layout.
+constexpr int kRedRows = 64, kRedGroups = 4;
+template <int TD>
+__global__ void __launch_bounds__(256)
+wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log, int Cd_log,
+                         long long s_dc, long long s_gc, long long s_tap, float* __restrict__ dst,
+                         const float* __restrict__ dbws, float* __restrict__ db, int G, int T, int SGN) {
+  __shared__ float part[kRedGroups][kRedRows][TD + 1];
+  const int tid = threadIdx.x;
+  const long long total = (long long)Mtot * Cd;
+  if (db) {
+    const int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
+    if (i < Cd_log) {
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) v += dbws[(long long)s * Cd + i];
+      db[i] = v;
+    }
+  }
+  const int gc0 = blockIdx.x * G, dc0 = blockIdx.y * TD;
+  const int RT = G * T;
+  constexpr int C4 = TD / 4;
+  const int slots = RT * C4;
+  for (int p = tid; p < slots * SGN; p += 256) {
+    const int sg = p / slots, sl = p - sg * slots;
+    const int r = sl / C4, c4 = sl - r * C4;
+    const int gl = r / T, tap = r - gl * T;
+    const int gc = gc0 + gl, dc = dc0 + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gc < Cg && dc < Cd) {
+      const float* src = ws + (long long)(tap * Cg + gc) * Cd + dc;
+      for (int sidx = sg; sidx < S; sidx += SGN) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (long long)sidx * total);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    float* q = &part[sg][r][c4 * 4];
+    q[0] = acc.x; q[1] = acc.y; q[2] = acc.z; q[3] = acc.w;
+  }
+  __syncthreads();
+  for (int o = tid; o < TD * RT; o += 256) {
+    const int dcl = o / RT, r = o - dcl * RT;
+    float v = part[0][r][dcl];
+    for (int sg = 1; sg < SGN; ++sg) v += part[sg][r][dcl];
+    const int gl = r / T, tap = r - gl * T;
+    const int gc = gc0 + gl, dc = dc0 + dcl;
+    if (gc < Cg_log && dc < Cd_log) dst[dc * s_dc + gc * s_gc + tap * s_tap] = v;
+  }
+}
+
 }  // namespace ali
 
 using namespace ali;
@@ -497,10 +549,27 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (rc) return rc;
   if (S > 1) {
     const long long total = (long long)d.Mtot * g->K;
-    int nb = (int)((total + 255) / 256);
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
-                       Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db);
+    const int T = g->R * g->S;
+    if (fast && T <= kRedRows) {
+      // tile: G gathered channels x T taps (>= 16 rows, <= 64) by 32 or 16 dense channels; grow G while the grid stays deep
+      int G = (16 + T - 1) / T;
+      auto nblk = [&](int G_, int TD_) { return (long long)((g->C + G_ - 1) / G_) * ((g->K + TD_ - 1) / TD_); };
+      while (2 * G * T <= kRedRows && nblk(2 * G, 32) >= 2 * kNumCU) G *= 2;
+      const int TD = nblk(G, 32) >= kNumCU ? 32 : 16;
+      const int SGN = S < kRedGroups ? S : kRedGroups;
+      dim3 rgrid((g->C + G - 1) / G, (g->K + TD - 1) / TD);
+      if (TD == 32)
+        hipLaunchKernelGGL(wgrad_reduce_tile_kernel<32>, rgrid, dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
+                           Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN);
+      else
+        hipLaunchKernelGGL(wgrad_reduce_tile_kernel<16>, rgrid, dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
+                           Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN);
+    } else {
+      int nb = (int)((total + 255) / 256);
+      if (nb > 4096) nb = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
+                         Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db);
+    }
     rc = check_launch("wgrad_reduce_kernel");
   }
   if (!rc && db && !fast)   // generic path: bias gradient by the stand-alone column-sum kernels

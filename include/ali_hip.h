@@ -133,10 +133,13 @@ int ali_rowmask_mul(const float* x, const float* mask, float* out, int32_t B, in
 int ali_dropout_mask(uint64_t seed, uint64_t offset, const int64_t* dev_counter, float p, float* out, int64_t n,
                      ali_stream_t stream);
 
-/* All masks of one iteration in one launch: segment j covers elements [seg_end[j-1], seg_end[j]) with drop
- * probability seg_p[j] (host arrays, n_seg <= 64); element i gets the draw ali_dropout_mask(offset 0) gives index i. */
+/* All masks of one iteration in one launch: segment j is a [rows][seg_cpad[j]] mask stored at elements
+ * [seg_end[j-1], seg_end[j]) with drop probability seg_p[j] (host arrays, n_seg <= 64).  Its first seg_clog[j] columns
+ * take, row-major, the draws ali_dropout_mask gives with offset = number of draws of the earlier segments; the
+ * remaining (channel padding) columns are 1. */
 int ali_dropout_mask_multi(uint64_t seed, const int64_t* dev_counter, const int64_t* seg_end, const float* seg_p,
-                           int32_t n_seg, float* out, ali_stream_t stream);
+                           const int32_t* seg_clog, const int32_t* seg_cpad, int32_t n_seg, float* out,
+                           ali_stream_t stream);
 
 /* nn.BatchNorm2d in training / eval mode (mnist.py:111,114,118,122).
  * stats: per-channel batch mean / biased var of (mask ? x*mask : x), running
