@@ -327,6 +327,165 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+// ---- float4 variants of the BatchNorm / column-sum passes (C % 4 == 0, < 2^31 elements): 16-byte accesses, 32-bit
+// index arithmetic, four rows in flight per thread.  Same partial layouts as the scalar kernels above.
+// MODE 0: (sum x~, sum x~^2)   MODE 1: (sum g~*xhat, sum g~)   MODE 2: column sums of x (row stride ld)
+template <int MODE>
+__global__ void __launch_bounds__(kEwBlock)
+rowreduce_vec_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ mask_in,
+                     const float* __restrict__ mask_pre, const float* __restrict__ mean,
+                     const float* __restrict__ invstd, unsigned rows, unsigned rows_per_img, unsigned C, unsigned ld,
+                     float* __restrict__ part) {
+  __shared__ float4 red1[kEwBlock], red2[kEwBlock];
+  const unsigned t = threadIdx.x;
+  const unsigned C4 = C >> 2, lanes_r = kEwBlock / C4;
+  const unsigned tr = t / C4, tc = (t - tr * C4) * 4;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (tr < lanes_r) {
+    float4 mu = s1, is = s1;
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const float4*>(mean + tc);
+      is = *reinterpret_cast<const float4*>(invstd + tc);
+    }
+    const unsigned stride = gridDim.x * lanes_r;
+    for (unsigned r0 = blockIdx.x * lanes_r + tr; r0 < rows; r0 += 4 * stride) {
+      float4 xv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned r = r0 + u * stride;
+        xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[u] = xv[u];
+        if (r < rows) {
+          xv[u] = *reinterpret_cast<const float4*>(x + (size_t)r * ld + tc);
+          if (MODE == 1) gv[u] = *reinterpret_cast<const float4*>(g + (size_t)r * ld + tc);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned r = r0 + u * stride;
+        if (r >= rows) break;
+        float4 a = xv[u];
+        if (MODE != 2 && (mask_in || mask_pre)) {
+          const unsigned img = r / rows_per_img;
+          if (mask_in) {
+            const float4 m = *reinterpret_cast<const float4*>(mask_in + (size_t)img * C + tc);
+            a.x *= m.x; a.y *= m.y; a.z *= m.z; a.w *= m.w;
+          }
+          if (MODE == 1 && mask_pre) {
+            const float4 m = *reinterpret_cast<const float4*>(mask_pre + (size_t)img * C + tc);
+            gv[u].x *= m.x; gv[u].y *= m.y; gv[u].z *= m.z; gv[u].w *= m.w;
+          }
+        }
+        if (MODE == 0) {
+          s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+          s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
+        } else if (MODE == 1) {
+          const float4 b = gv[u];
+          s1.x += b.x * (a.x - mu.x) * is.x; s1.y += b.y * (a.y - mu.y) * is.y;
+          s1.z += b.z * (a.z - mu.z) * is.z; s1.w += b.w * (a.w - mu.w) * is.w;
+          s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+        } else {
+          s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+        }
+      }
+    }
+  }
+  red1[t] = s1;
+  if (MODE != 2) red2[t] = s2;
+  __syncthreads();
+  if (tr == 0) {
+    for (unsigned j = 1; j < lanes_r; ++j) {
+      const float4 a = red1[j * C4 + t];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      if (MODE != 2) {
+        const float4 b = red2[j * C4 + t];
+        s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+      }
+    }
+    if (MODE == 2) {
+      *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C + tc) = s1;
+    } else {
+      *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + tc) = s1;
+      *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + tc) = s2;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kEwBlock)
+bn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
+                    const float* __restrict__ mask_in, const float* __restrict__ mask_post, float* __restrict__ out,
+                    unsigned n4, unsigned rows_per_img, unsigned C) {
+  const unsigned C4 = C >> 2, step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
+    const unsigned row = i / C4, c = (i - row * C4) * 4;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 a = *reinterpret_cast<const float4*>(sc + c), b = *reinterpret_cast<const float4*>(sh + c);
+    const unsigned img = (mask_in || mask_post) ? row / rows_per_img : 0u;
+    if (mask_in) {
+      const float4 m = *reinterpret_cast<const float4*>(mask_in + (size_t)img * C + c);
+      v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    }
+    v.x = v.x * a.x + b.x; v.y = v.y * a.y + b.y; v.z = v.z * a.z + b.z; v.w = v.w * a.w + b.w;
+    if (mask_post) {
+      const float4 m = *reinterpret_cast<const float4*>(mask_post + (size_t)img * C + c);
+      v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+__global__ void __launch_bounds__(kEwBlock)
+bn_bwd_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ mask_in,
+                        const float* __restrict__ mask_pre, const float* __restrict__ mean,
+                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                        const float* __restrict__ dgamma, const float* __restrict__ dbeta, unsigned n4,
+                        unsigned rows_per_img, unsigned C, float inv_count, int batch_stats, float slope,
+                        float* __restrict__ gx) {
+  const unsigned C4 = C >> 2, step = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
+    const unsigned row = i / C4, c = (i - row * C4) * 4;
+    const float4 xr4 = reinterpret_cast<const float4*>(x)[i];
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    const unsigned img = (mask_in || mask_pre) ? row / rows_per_img : 0u;
+    float mi[4] = {1.f, 1.f, 1.f, 1.f}, mp[4] = {1.f, 1.f, 1.f, 1.f};
+    if (mask_in) {
+      const float4 m = *reinterpret_cast<const float4*>(mask_in + (size_t)img * C + c);
+      mi[0] = m.x; mi[1] = m.y; mi[2] = m.z; mi[3] = m.w;
+    }
+    if (mask_pre) {
+      const float4 m = *reinterpret_cast<const float4*>(mask_pre + (size_t)img * C + c);
+      mp[0] = m.x; mp[1] = m.y; mp[2] = m.z; mp[3] = m.w;
+    }
+    const float xr[4] = {xr4.x, xr4.y, xr4.z, xr4.w}, gr[4] = {g4.x, g4.y, g4.z, g4.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xv = xr[k] * mi[k];
+      const float is = invstd[c + k];
+      const float gm = gamma ? gamma[c + k] : 1.f;
+      float r = gr[k] * mp[k];
+      if (batch_stats) r -= (dbeta[c + k] + (xv - mean[c + k]) * is * dgamma[c + k]) * inv_count;
+      r *= gm * is;
+      r *= mi[k];
+      if (slope >= 0.f) r *= (xr[k] > 0.f ? 1.f : slope);
+      o[k] = r;
+    }
+    reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool vec_ok(long long rows, int C) {
+  return (C % 4) == 0 && C >= 4 && C <= 4 * kEwBlock && rows * C < (1LL << 31);
+}
+static int reduce_blocks_vec(long long rows, int C) {
+  const int lanes_r = kEwBlock / (C / 4);
+  long long nb = (rows + (long long)lanes_r * 8 - 1) / ((long long)lanes_r * 8);
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
 // ---- BCE with logits against a constant target (single block; B <= a few thousand)
 __global__ void bce_logits_kernel(const float* __restrict__ logit, int B, float target, float gscale,
                                   float* __restrict__ out2, float* __restrict__ glogit) {
@@ -457,10 +616,16 @@ static int reduce_blocks(long long rows, int C) {
 extern "C" int ali_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, float* out, void* ws, size_t ws_bytes,
                           ali_stream_t stream) {
   if (!x || !out || rows <= 0 || C <= 0 || ld < C) { set_error("ali_colsum: bad argument"); return ALI_ERR_BAD_ARG; }
-  const int nb = reduce_blocks(rows, C);
+  const bool vec = vec_ok(rows, C) && (ld % 4) == 0 && (long long)rows * ld < (1LL << 31) && aligned16(x);
+  const int nb = vec ? reduce_blocks_vec(rows, C) : reduce_blocks(rows, C);
   if (!ws || ws_bytes < (size_t)nb * C * sizeof(float)) { set_error("ali_colsum: workspace too small"); return ALI_ERR_WORKSPACE; }
   float* part = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, (long long)rows, C, ld, part);
+  if (vec)
+    hipLaunchKernelGGL(rowreduce_vec_kernel<2>, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (unsigned)rows, 1u, (unsigned)C, (unsigned)ld, part);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, (long long)rows, C, ld, part);
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, out);
   return check_launch("colsum");
 }
@@ -523,10 +688,15 @@ extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_
     return ALI_ERR_BAD_ARG;
   }
   const long long rows = (long long)B * rows_per_img;
-  const int nb = reduce_blocks(rows, C);
+  const bool vec = vec_ok(rows, C) && aligned16(x) && (!mask || aligned16(mask));
+  const int nb = vec ? reduce_blocks_vec(rows, C) : reduce_blocks(rows, C);
   if (!ws || ws_bytes < (size_t)nb * 2 * C * sizeof(float)) { set_error("ali_bn_stats: workspace too small"); return ALI_ERR_WORKSPACE; }
   float* part = reinterpret_cast<float*>(ws);
-  if (training)
+  if (training && vec)
+    hipLaunchKernelGGL(rowreduce_vec_kernel<0>, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, (const float*)nullptr, mask,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (unsigned)rows,
+                       (unsigned)rows_per_img, (unsigned)C, (unsigned)C, part);
+  else if (training)
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, mask, rows, rows_per_img, C, part);
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, rows, gamma, beta,
                      running_mean, running_var, momentum, eps, training, mean, invstd, sc, sh);
@@ -538,8 +708,13 @@ extern "C" int ali_bn_apply(const float* x, const float* sc, const float* sh, co
                             ali_stream_t stream) {
   if (!x || !sc || !sh || !out || B <= 0 || rows_per_img <= 0 || C <= 0) { set_error("ali_bn_apply: bad argument"); return ALI_ERR_BAD_ARG; }
   const long long n = (long long)B * rows_per_img * C;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in, mask_post, out, n,
-                     rows_per_img, C);
+  if (vec_ok((long long)B * rows_per_img, C) && aligned16(x) && aligned16(out) && (!mask_in || aligned16(mask_in)) &&
+      (!mask_post || aligned16(mask_post)))
+    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(ew_grid(n / 4)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in,
+                       mask_post, out, (unsigned)(n / 4), (unsigned)rows_per_img, (unsigned)C);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in, mask_post, out, n,
+                       rows_per_img, C);
   return check_launch("bn_apply_kernel");
 }
 
@@ -552,16 +727,29 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
     return ALI_ERR_BAD_ARG;
   }
   const long long rows = (long long)B * rows_per_img;
-  const int nb = reduce_blocks(rows, C);
+  const bool vec = vec_ok(rows, C) && aligned16(x) && aligned16(g) && (!gx || aligned16(gx)) &&
+                   (!mask_in || aligned16(mask_in)) && (!mask_pre || aligned16(mask_pre)) && aligned16(mean) &&
+                   aligned16(invstd);
+  const int nb = vec ? reduce_blocks_vec(rows, C) : reduce_blocks(rows, C);
   if (!ws || ws_bytes < (size_t)nb * 2 * C * sizeof(float)) { set_error("ali_bn_bwd: workspace too small"); return ALI_ERR_WORKSPACE; }
   float* part = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean, invstd,
-                     rows, rows_per_img, C, part);
+  if (vec)
+    hipLaunchKernelGGL(rowreduce_vec_kernel<1>, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean,
+                       invstd, (unsigned)rows, (unsigned)rows_per_img, (unsigned)C, (unsigned)C, part);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean, invstd,
+                       rows, rows_per_img, C, part);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, dgamma, dbeta);
   if (gx) {
     const long long n = rows * C;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean,
-                       invstd, gamma, dgamma, dbeta, n, rows_per_img, C, 1.f / (float)rows, batch_stats, lrelu_slope, gx);
+    if (vec)
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(ew_grid(n / 4)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in,
+                         mask_pre, mean, invstd, gamma, dgamma, dbeta, (unsigned)(n / 4), (unsigned)rows_per_img,
+                         (unsigned)C, 1.f / (float)rows, batch_stats, lrelu_slope, gx);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre,
+                         mean, invstd, gamma, dgamma, dbeta, n, rows_per_img, C, 1.f / (float)rows, batch_stats,
+                         lrelu_slope, gx);
   }
   return check_launch("bn_bwd");
 }

@@ -427,13 +427,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mto
 // channels] tile.  Slab rows are read as TD-float runs (float4 per lane), the S slabs are split over SGN thread groups
 // (fixed order inside a group, groups combined in order: deterministic), and the tile is written back through LDS so
 // that each dense channel stores one contiguous run of G*T floats of the reference weight layout.
-constexpr int kRedRows = 64, kRedGroups = 4;
+constexpr int kRedRows = 64, kRedGroups = 16, kRedLds = 256;   // rows per tile, slab groups, groups*rows bound
 template <int TD>
 __global__ void __launch_bounds__(256)
 wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log, int Cd_log,
                          long long s_dc, long long s_gc, long long s_tap, float* __restrict__ dst,
                          const float* __restrict__ dbws, float* __restrict__ db, int G, int T, int SGN) {
-  __shared__ float part[kRedGroups][kRedRows][TD + 1];
+  __shared__ float part[kRedLds * (TD + 1)];   // [SGN][RT][TD+1], SGN*RT <= kRedLds
   const int tid = threadIdx.x;
   const long long total = (long long)Mtot * Cd;
   if (db) {
@@ -456,19 +456,30 @@ wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gc < Cg && dc < Cd) {
       const float* src = ws + (long long)(tap * Cg + gc) * Cd + dc;
-      for (int sidx = sg; sidx < S; sidx += SGN) {
+      int sidx = sg;
+      for (; sidx + 3 * SGN < S; sidx += 4 * SGN) {      // four independent loads in flight, summed in slab order
+        const float4 v0 = *reinterpret_cast<const float4*>(src + (long long)sidx * total);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + (long long)(sidx + SGN) * total);
+        const float4 v2 = *reinterpret_cast<const float4*>(src + (long long)(sidx + 2 * SGN) * total);
+        const float4 v3 = *reinterpret_cast<const float4*>(src + (long long)(sidx + 3 * SGN) * total);
+        acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x;
+        acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
+        acc.z = (((acc.z + v0.z) + v1.z) + v2.z) + v3.z;
+        acc.w = (((acc.w + v0.w) + v1.w) + v2.w) + v3.w;
+      }
+      for (; sidx < S; sidx += SGN) {
         const float4 v = *reinterpret_cast<const float4*>(src + (long long)sidx * total);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     }
-    float* q = &part[sg][r][c4 * 4];
+    float* q = &part[(sg * RT + r) * (TD + 1) + c4 * 4];
     q[0] = acc.x; q[1] = acc.y; q[2] = acc.z; q[3] = acc.w;
   }
   __syncthreads();
   for (int o = tid; o < TD * RT; o += 256) {
     const int dcl = o / RT, r = o - dcl * RT;
-    float v = part[0][r][dcl];
-    for (int sg = 1; sg < SGN; ++sg) v += part[sg][r][dcl];
+    float v = part[r * (TD + 1) + dcl];
+    for (int sg = 1; sg < SGN; ++sg) v += part[(sg * RT + r) * (TD + 1) + dcl];
     const int gl = r / T, tap = r - gl * T;
     const int gc = gc0 + gl, dc = dc0 + dcl;
     if (gc < Cg_log && dc < Cd_log) dst[dc * s_dc + gc * s_gc + tap * s_tap] = v;
@@ -556,7 +567,9 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
       auto nblk = [&](int G_, int TD_) { return (long long)((g->C + G_ - 1) / G_) * ((g->K + TD_ - 1) / TD_); };
       while (2 * G * T <= kRedRows && nblk(2 * G, 32) >= 2 * kNumCU) G *= 2;
       const int TD = nblk(G, 32) >= kNumCU ? 32 : 16;
-      const int SGN = S < kRedGroups ? S : kRedGroups;
+      int SGN = kRedLds / (G * T);
+      if (SGN > kRedGroups) SGN = kRedGroups;
+      if (SGN > S) SGN = S;
       dim3 rgrid((g->C + G - 1) / G, (g->K + TD - 1) / TD);
       if (TD == 32)
         hipLaunchKernelGGL(wgrad_reduce_tile_kernel<32>, rgrid, dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,

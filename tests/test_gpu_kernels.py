@@ -156,11 +156,12 @@ def test_fused_epilogue_mask_and_dact():
     close(nchw(dx), ref, what="fused dgrad epilogue")
 
 
+@pytest.mark.parametrize("shape", [(7, 64, 5), (33, 32, 9), (5, 6, 4)])     # float4 kernels / scalar kernels (C % 4)
 @pytest.mark.parametrize("order", ["bn_drop", "drop_bn", "bn", "eval"])
-def test_batchnorm_fwd_bwd(order):
+def test_batchnorm_fwd_bwd(order, shape):
     ops = _ops()
     g = torch.Generator().manual_seed(3)
-    B, C, H = 7, 64, 5
+    B, C, H = shape
     y = torch.randn(B, C, H, H, generator=g) * 2 + 0.5
     mask = (torch.rand(B, C, generator=g) > 0.5).float() * 2
     gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
@@ -223,6 +224,9 @@ def test_bce_adam_colsum_dropout():
     assert (pd.cpu() - pr.detach()).abs().max().item() < 1e-7
     x = torch.randn(3001, 40, generator=g)
     close(ops.colsum(3001, 40, 40, x.cuda()), x.sum(0), rtol=1e-5, what="colsum")
+    close(ops.colsum(3001, 37, 40, x.cuda()), x[:, :37].sum(0), rtol=1e-5, what="colsum scalar path")
+    xw = torch.randn(515, 1024, generator=g)
+    close(ops.colsum(515, 1024, 1024, xw.cuda()), xw.sum(0), rtol=1e-5, what="colsum wide")
     mk = ops.dropout_mask(7, 0, 0.2, 4096, 64, torch.device("cuda"))
     vals = torch.unique(mk).cpu()
     assert set(np.round(vals.numpy(), 4).tolist()) == {0.0, 1.25}
