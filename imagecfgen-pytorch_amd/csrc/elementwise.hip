@@ -411,26 +411,28 @@ rowreduce_vec_kernel(const float* __restrict__ x, const float* __restrict__ g, c
   }
 }
 
+// elementwise passes: thread (tr, tc) owns channels [4tc, 4tc+4) of rows tr, tr+stride, ...: the per-channel
+// constants are loaded once, the only division left is row -> image for the Dropout2d masks
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldc4(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }  // any alignment
+
 __global__ void __launch_bounds__(kEwBlock)
 bn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                     const float* __restrict__ mask_in, const float* __restrict__ mask_post, float* __restrict__ out,
-                    unsigned n4, unsigned rows_per_img, unsigned C) {
-  const unsigned C4 = C >> 2, step = gridDim.x * blockDim.x;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
-    const unsigned row = i / C4, c = (i - row * C4) * 4;
-    float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 a = *reinterpret_cast<const float4*>(sc + c), b = *reinterpret_cast<const float4*>(sh + c);
-    const unsigned img = (mask_in || mask_post) ? row / rows_per_img : 0u;
-    if (mask_in) {
-      const float4 m = *reinterpret_cast<const float4*>(mask_in + (size_t)img * C + c);
-      v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-    }
+                    unsigned rows, unsigned rows_per_img, unsigned C) {
+  const unsigned C4 = C >> 2, lanes_r = kEwBlock / C4;
+  const unsigned tr = threadIdx.x / C4, c = (threadIdx.x - tr * C4) * 4;
+  if (tr >= lanes_r) return;
+  const float4 a = ldc4(sc + c), b = ldc4(sh + c);
+  const unsigned stride = gridDim.x * lanes_r;
+  for (unsigned r = blockIdx.x * lanes_r + tr; r < rows; r += stride) {
+    float4 v = ld4(x + (size_t)r * C + c);
+    const unsigned img = (mask_in || mask_post) ? r / rows_per_img : 0u;
+    if (mask_in) v = mul4(v, ld4(mask_in + (size_t)img * C + c));
     v.x = v.x * a.x + b.x; v.y = v.y * a.y + b.y; v.z = v.z * a.z + b.z; v.w = v.w * a.w + b.w;
-    if (mask_post) {
-      const float4 m = *reinterpret_cast<const float4*>(mask_post + (size_t)img * C + c);
-      v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-    }
-    reinterpret_cast<float4*>(out)[i] = v;
+    if (mask_post) v = mul4(v, ld4(mask_post + (size_t)img * C + c));
+    *reinterpret_cast<float4*>(out + (size_t)r * C + c) = v;
   }
 }
 
@@ -438,39 +440,37 @@ __global__ void __launch_bounds__(kEwBlock)
 bn_bwd_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ mask_in,
                         const float* __restrict__ mask_pre, const float* __restrict__ mean,
                         const float* __restrict__ invstd, const float* __restrict__ gamma,
-                        const float* __restrict__ dgamma, const float* __restrict__ dbeta, unsigned n4,
+                        const float* __restrict__ dgamma, const float* __restrict__ dbeta, unsigned rows,
                         unsigned rows_per_img, unsigned C, float inv_count, int batch_stats, float slope,
                         float* __restrict__ gx) {
-  const unsigned C4 = C >> 2, step = gridDim.x * blockDim.x;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
-    const unsigned row = i / C4, c = (i - row * C4) * 4;
-    const float4 xr4 = reinterpret_cast<const float4*>(x)[i];
-    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
-    const unsigned img = (mask_in || mask_pre) ? row / rows_per_img : 0u;
-    float mi[4] = {1.f, 1.f, 1.f, 1.f}, mp[4] = {1.f, 1.f, 1.f, 1.f};
-    if (mask_in) {
-      const float4 m = *reinterpret_cast<const float4*>(mask_in + (size_t)img * C + c);
-      mi[0] = m.x; mi[1] = m.y; mi[2] = m.z; mi[3] = m.w;
+  const unsigned C4 = C >> 2, lanes_r = kEwBlock / C4;
+  const unsigned tr = threadIdx.x / C4, c = (threadIdx.x - tr * C4) * 4;
+  if (tr >= lanes_r) return;
+  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 is = ldc4(invstd + c), mu = ldc4(mean + c), gm = gamma ? ldc4(gamma + c) : one;
+  const float4 dg = ldc4(dgamma + c), db = ldc4(dbeta + c);
+  const float4 k = mul4(gm, is);
+  const unsigned stride = gridDim.x * lanes_r;
+  for (unsigned r = blockIdx.x * lanes_r + tr; r < rows; r += stride) {
+    const float4 xr = ld4(x + (size_t)r * C + c);
+    float4 gv = ld4(g + (size_t)r * C + c);
+    const unsigned img = (mask_in || mask_pre) ? r / rows_per_img : 0u;
+    const float4 mi = mask_in ? ld4(mask_in + (size_t)img * C + c) : one;
+    if (mask_pre) gv = mul4(gv, ld4(mask_pre + (size_t)img * C + c));
+    const float4 xv = mul4(xr, mi);
+    float4 o = gv;
+    if (batch_stats) {
+      o.x -= (db.x + (xv.x - mu.x) * is.x * dg.x) * inv_count;
+      o.y -= (db.y + (xv.y - mu.y) * is.y * dg.y) * inv_count;
+      o.z -= (db.z + (xv.z - mu.z) * is.z * dg.z) * inv_count;
+      o.w -= (db.w + (xv.w - mu.w) * is.w * dg.w) * inv_count;
     }
-    if (mask_pre) {
-      const float4 m = *reinterpret_cast<const float4*>(mask_pre + (size_t)img * C + c);
-      mp[0] = m.x; mp[1] = m.y; mp[2] = m.z; mp[3] = m.w;
+    o = mul4(mul4(o, k), mi);
+    if (slope >= 0.f) {
+      o.x *= xr.x > 0.f ? 1.f : slope; o.y *= xr.y > 0.f ? 1.f : slope;
+      o.z *= xr.z > 0.f ? 1.f : slope; o.w *= xr.w > 0.f ? 1.f : slope;
     }
-    const float xr[4] = {xr4.x, xr4.y, xr4.z, xr4.w}, gr[4] = {g4.x, g4.y, g4.z, g4.w};
-    float o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float xv = xr[k] * mi[k];
-      const float is = invstd[c + k];
-      const float gm = gamma ? gamma[c + k] : 1.f;
-      float r = gr[k] * mp[k];
-      if (batch_stats) r -= (dbeta[c + k] + (xv - mean[c + k]) * is * dgamma[c + k]) * inv_count;
-      r *= gm * is;
-      r *= mi[k];
-      if (slope >= 0.f) r *= (xr[k] > 0.f ? 1.f : slope);
-      o[k] = r;
-    }
-    reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(gx + (size_t)r * C + c) = o;
   }
 }
 
@@ -711,7 +711,7 @@ extern "C" int ali_bn_apply(const float* x, const float* sc, const float* sh, co
   if (vec_ok((long long)B * rows_per_img, C) && aligned16(x) && aligned16(out) && (!mask_in || aligned16(mask_in)) &&
       (!mask_post || aligned16(mask_post)))
     hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(ew_grid(n / 4)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in,
-                       mask_post, out, (unsigned)(n / 4), (unsigned)rows_per_img, (unsigned)C);
+                       mask_post, out, (unsigned)((long long)B * rows_per_img), (unsigned)rows_per_img, (unsigned)C);
   else
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in, mask_post, out, n,
                        rows_per_img, C);
@@ -744,7 +744,7 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
     const long long n = rows * C;
     if (vec)
       hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(ew_grid(n / 4)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in,
-                         mask_pre, mean, invstd, gamma, dgamma, dbeta, (unsigned)(n / 4), (unsigned)rows_per_img,
+                         mask_pre, mean, invstd, gamma, dgamma, dbeta, (unsigned)rows, (unsigned)rows_per_img,
                          (unsigned)C, 1.f / (float)rows, batch_stats, lrelu_slope, gx);
     else
       hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre,
