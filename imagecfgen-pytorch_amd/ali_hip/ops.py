@@ -22,11 +22,12 @@ def set_workspace_bytes(n: int):
 
 
 def workspace(device) -> torch.Tensor:
-    """One scratch slab per device, reused stream-ordered by every kernel."""
+    """One scratch slab per device, reused stream-ordered by every kernel.  Zero-filled once: its first 4 KiB are the
+    split-K arrival counters of the GEMM kernels, which every launch leaves at zero (include/ali_hip.h)."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     ws = _WS.get(key)
     if ws is None or ws.numel() < _WS_BYTES:
-        ws = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+        ws = torch.zeros(_WS_BYTES, dtype=torch.uint8, device=device)
         _WS[key] = ws
     return ws
 

@@ -24,6 +24,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kMaxTaps = 28;   // 5x5 kernels are the largest on the path
 constexpr int kNumCU = 256;
 
+// The first kWsReserved bytes of every caller-provided workspace hold the split-K arrival counters of the GEMM
+// kernels (zero-filled by the caller once, left zero by every launch); all scratch data lives behind them.
+constexpr size_t kWsReserved = ALI_WS_RESERVED;
+inline void* ws_payload(void* ws) { return ws ? static_cast<char*>(ws) + kWsReserved : nullptr; }
+inline size_t ws_payload_bytes(size_t bytes) { return bytes > kWsReserved ? bytes - kWsReserved : 0; }
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   if (act == ALI_ACT_LEAKY) return v > 0.f ? v : v * slope;
   if (act == ALI_ACT_TANH) return tanhf(v);

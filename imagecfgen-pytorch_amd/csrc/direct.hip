@@ -340,6 +340,8 @@ extern "C" int ali_tconv1_dgrad(const float* small, int32_t sstride, const float
 extern "C" int ali_tconv1_wgrad(const float* big, const float* small, int32_t sstride, int32_t nc, float* dw, int64_t s_k,
                                 int64_t s_tap, int64_t s_c, int32_t B, int32_t P, int32_t Q, int32_t K, int32_t R,
                                 int32_t S, int32_t pad, void* ws, size_t ws_bytes, ali_stream_t stream) {
+  ws = ws_payload(ws);
+  ws_bytes = ws_payload_bytes(ws_bytes);
   const int H = P + R - 1 - 2 * pad, W = Q + S - 1 - 2 * pad;
   if (!big || !small || !dw || sstride < 1 || nc < 1 || nc > T1W_MAXNC || nc > sstride) {
     set_error("ali_tconv1_wgrad: bad argument");

@@ -615,6 +615,8 @@ static int reduce_blocks(long long rows, int C) {
 
 extern "C" int ali_colsum(const float* x, int64_t rows, int32_t C, int32_t ld, float* out, void* ws, size_t ws_bytes,
                           ali_stream_t stream) {
+  ws = ws_payload(ws);
+  ws_bytes = ws_payload_bytes(ws_bytes);
   if (!x || !out || rows <= 0 || C <= 0 || ld < C) { set_error("ali_colsum: bad argument"); return ALI_ERR_BAD_ARG; }
   const bool vec = vec_ok(rows, C) && (ld % 4) == 0 && (long long)rows * ld < (1LL << 31) && aligned16(x);
   const int nb = vec ? reduce_blocks_vec(rows, C) : reduce_blocks(rows, C);
@@ -682,6 +684,8 @@ extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_
                             const float* gamma, const float* beta, float* running_mean, float* running_var,
                             float momentum, float eps, int32_t training, float* mean, float* invstd, float* sc,
                             float* sh, void* ws, size_t ws_bytes, ali_stream_t stream) {
+  ws = ws_payload(ws);
+  ws_bytes = ws_payload_bytes(ws_bytes);
   if (!x || B <= 0 || rows_per_img <= 0 || C <= 0 || C > kEwBlock || !mean || !invstd || !sc || !sh ||
       (!training && (!running_mean || !running_var))) {
     set_error("ali_bn_stats: bad argument (C must be <= 256)");
@@ -722,6 +726,8 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
                           const float* mean, const float* invstd, const float* gamma, int32_t B,
                           int32_t rows_per_img, int32_t C, int32_t batch_stats, float lrelu_slope, float* dgamma,
                           float* dbeta, float* gx, void* ws, size_t ws_bytes, ali_stream_t stream) {
+  ws = ws_payload(ws);
+  ws_bytes = ws_payload_bytes(ws_bytes);
   if (!x || !g || !mean || !invstd || !dgamma || !dbeta || B <= 0 || rows_per_img <= 0 || C <= 0 || C > kEwBlock) {
     set_error("ali_bn_bwd: bad argument");
     return ALI_ERR_BAD_ARG;

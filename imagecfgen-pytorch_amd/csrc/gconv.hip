@@ -66,6 +66,7 @@ struct GDesc {
   const float* w;
   float* out;
   float* ws;
+  int* ctr;            // split-K: one arrival counter per output tile (zero between launches)
   AliEpilogue ep;
   int B, Hin, Win, Cin;
   int Hout, Wout, Cout, ldo;
@@ -451,9 +452,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   // epilogue: acc(row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31).  Row offsets are fetched from LDS in one
   // batch, the optional mask / act' operands in one batch of global loads (no branch, no wait per element).
   const AliEpilogue& ep = d.ep;
-  const bool partial = d.splitk > 1;
-  float* outp = partial ? d.ws + (long long)blockIdx.z * d.out_elems : d.out;
-  auto run_epilogue = [&](auto has_mask_t, auto has_dact_t) {
+  auto run_epilogue = [&](auto has_mask_t, auto has_dact_t, const bool partial, float* outp) {
     constexpr bool HAS_MASK = decltype(has_mask_t)::value, HAS_DACT = decltype(has_dact_t)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -490,7 +489,10 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
               if (HAS_MASK) v *= mk[q];
               if (HAS_DACT) v *= act_grad_from_output(dy[q], ep.dact, ep.dslope);
             }
-            if (nok && roff[q] >= 0) outp[roff[q] + n] = v;
+            if (nok && roff[q] >= 0) {
+              if (partial) __hip_atomic_store(outp + roff[q] + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else outp[roff[q] + n] = v;
+            }
           }
         }
       }
@@ -498,29 +500,68 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
-  const bool hm = !partial && ep.mask != nullptr, hd = !partial && ep.dact_y != nullptr;
-  if (hm && hd) run_epilogue(T_{}, T_{});
-  else if (hm) run_epilogue(T_{}, F_{});
-  else if (hd) run_epilogue(F_{}, T_{});
-  else run_epilogue(F_{}, F_{});
-}
-
-// out = epilogue(sum_s ws[s]) over the flat NHWC output
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long out_elems, float* __restrict__ out,
-                                     AliEpilogue ep, int ldo, int rows_per_img) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long step = (long long)gridDim.x * blockDim.x;
-  for (; i < out_elems; i += step) {
-    float v = 0.f;
-    for (int s = 0; s < S; ++s) v += ws[(long long)s * out_elems + i];
-    const int n = (int)(i % ldo);
-    const long long pix = i / ldo;
-    if (ep.bias) v += ep.bias[n];
-    v = apply_act(v, ep.act, ep.slope);
-    if (ep.mask) v *= ep.mask[(pix / rows_per_img) * ep.mask_ld + n];
-    if (ep.dact_y) v *= act_grad_from_output(ep.dact_y[i], ep.dact, ep.dslope);
-    out[i] = v;
+  if (d.splitk > 1) {
+    // split-K: every block stores its raw partial tile in its slab; the block that arrives last at the tile's
+    // counter sums the slabs in slab order (deterministic whichever block that is) and runs the real epilogue.
+    // Slab stores / loads are device-scope (sc1) accesses -- written through to memory, never served from another
+    // XCD's stale L2 line -- so no cache-wide release / acquire fence is needed, only "my stores have completed".
+    run_epilogue(F_{}, F_{}, true, d.ws + (long long)blockIdx.z * d.out_elems);
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (t == 0) {
+      int* c = d.ctr + (blockIdx.y * gridDim.x + blockIdx.x);
+      const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = arrived == d.splitk - 1;
+      if (s_last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all blocks have arrived
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // all 16 rows x 4 slabs of a sub-tile are requested before the first one is consumed (the loads bypass L2:
+    // one memory latency per 4 slabs instead of one per slab).  Buffer loads: 32-bit offsets, out-of-range -> 0.
+    const __amdgpu_buffer_rsrc_t rws =
+        __builtin_amdgcn_make_buffer_rsrc((void*)d.ws, 0, (unsigned)(d.splitk * d.out_elems * 4), 0x00020000);
+    constexpr int kSc1 = 16;          // cache policy: device scope
+    const unsigned slab_bytes = (unsigned)(d.out_elems * 4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        unsigned voff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = s_rowoff[wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+          voff[r] = (n < d.Cout && ro >= 0) ? (unsigned)(ro + n) * 4u : 0xFFFFFF00u;
+        }
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        for (int sl0 = 0; sl0 < d.splitk; sl0 += 4) {
+          float tmp[4][16];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            // slabs past the last one: soffset beyond num_records -> 0
+            const unsigned soff = (sl0 + u < d.splitk) ? (unsigned)(sl0 + u) * slab_bytes : 0xFFFFFF00u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              tmp[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, (int)voff[r], (int)soff, kSc1));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += tmp[u][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = v[r];
+      }
+    }
   }
+  const bool hm = ep.mask != nullptr, hd = ep.dact_y != nullptr;
+  if (hm && hd) run_epilogue(T_{}, T_{}, false, d.out);
+  else if (hm) run_epilogue(T_{}, F_{}, false, d.out);
+  else if (hd) run_epilogue(F_{}, T_{}, false, d.out);
+  else run_epilogue(F_{}, F_{}, false, d.out);
 }
 
 struct TileCfg { int bm, bn; };
@@ -583,17 +624,20 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     S = (int)((2 * kNumCU + blocks - 1) / blocks);
     if (S > max_nkt / 4) S = max_nkt / 4;
     if (S > 32) S = 32;
-    while (S > 1 && (size_t)S * d.out_elems * sizeof(float) > ws_bytes) --S;
+    while (S > 1 && (size_t)S * d.out_elems * sizeof(float) > ws_payload_bytes(ws_bytes)) --S;
     if (S < 1) S = 1;
   }
   {
     const char* fs = getenv("ALI_SPLITK");
-    if (fs && atoi(fs) > 0) S = atoi(fs);
+    if (fs && atoi(fs) > 0 && (size_t)atoi(fs) * d.out_elems * sizeof(float) <= ws_payload_bytes(ws_bytes)) S = atoi(fs);
   }
+  if (blocks > (long long)(kWsReserved / sizeof(int)) || !ws) S = 1;   // one arrival counter per tile
+  while (S > 1 && (long long)S * d.out_elems * 4 >= 0xFF000000LL) --S;  // slabs addressed with 32-bit byte offsets
   d.splitk = S;
   d.kt_per_split = (max_nkt + S - 1) / S;
   if (d.kt_per_split < 1) d.kt_per_split = 1;
-  d.ws = reinterpret_cast<float*>(ws);
+  d.ctr = reinterpret_cast<int*>(ws);
+  d.ws = reinterpret_cast<float*>(ws_payload(ws));
   dim3 grid(tiles, ntile_n, S), block(256);
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
 #define LAUNCH(BM_, BN_, WMM, WNN)                                                                    \
@@ -609,17 +653,7 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   else if (tc.bm == 64 && tc.bn == 128) LAUNCH(64, 128, 2, 2);
   else LAUNCH(64, 64, 2, 2);
 #undef LAUNCH
-  int rc = check_launch("gconv_kernel");
-  if (rc) return rc;
-  if (S > 1) {
-    long long n = d.out_elems;
-    int nb = (int)((n + 255) / 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, d.ws, S, d.out_elems, d.out, d.ep, d.ldo,
-                       d.Hout * d.Wout);
-    rc = check_launch("splitk_reduce_kernel");
-  }
-  return rc;
+  return check_launch("gconv_kernel");
 }
 
 static bool geom_ok(const AliConvGeom* g) {
@@ -644,9 +678,9 @@ extern "C" int ali_version(void) { return 1; }
 
 extern "C" size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which) {
   if (!geom_ok(g)) return 0;
-  if (which == 0) return (size_t)32 * g->B * g->P * g->Q * g->K * sizeof(float);
-  if (which == 1) return (size_t)32 * g->B * g->H * g->W * g->C * sizeof(float);
-  return (size_t)64 * g->R * g->S * g->C * g->K * sizeof(float);
+  if (which == 0) return kWsReserved + (size_t)32 * g->B * g->P * g->Q * g->K * sizeof(float);
+  if (which == 1) return kWsReserved + (size_t)32 * g->B * g->H * g->W * g->C * sizeof(float);
+  return kWsReserved + (size_t)64 * g->R * g->S * g->C * g->K * sizeof(float);
 }
 
 extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,

@@ -498,6 +498,10 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     return ALI_ERR_BAD_ARG;
   }
   hipStream_t stream = (hipStream_t)stream_;
+  void* const ws_all = ws;
+  const size_t ws_all_bytes = ws_bytes;
+  ws = ws_payload(ws);                      // the workspace head holds the GEMM kernels' split-K counters
+  ws_bytes = ws_payload_bytes(ws_bytes);
   WDesc d;
   memset(&d, 0, sizeof(d));
   d.x = x; d.dy = dy; d.dst = dst; d.ws = reinterpret_cast<float*>(ws);
@@ -586,6 +590,6 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     rc = check_launch("wgrad_reduce_kernel");
   }
   if (!rc && db && !fast)   // generic path: bias gradient by the stand-alone column-sum kernels
-    rc = ali_colsum(dy, (int64_t)d.npix, Cd_log, g->K, db, ws, ws_bytes, stream_);
+    rc = ali_colsum(dy, (int64_t)d.npix, Cd_log, g->K, db, ws_all, ws_all_bytes, stream_);
   return rc;
 }

@@ -14,7 +14,10 @@
  *   - every function is stream ordered, never allocates, never synchronises,
  *     and returns 0 or a negative AliStatus; ali_last_error() gives the text.
  *   - `ws` is caller-provided scratch (>= the matching *_workspace_bytes());
- *     it may be reused by the next call on the same stream.
+ *     it may be reused by the next call on the same stream, not by concurrent
+ *     streams.  Its first ALI_WS_RESERVED bytes are the split-K arrival
+ *     counters of the GEMM kernels: zero-fill a new workspace once
+ *     (hipMemset); every launch leaves them at zero again.
  */
 #ifndef ALI_HIP_H
 #define ALI_HIP_H
@@ -27,6 +30,7 @@ extern "C" {
 #endif
 
 typedef void* ali_stream_t; /* hipStream_t */
+#define ALI_WS_RESERVED 4096
 
 typedef enum {
   ALI_OK = 0,
