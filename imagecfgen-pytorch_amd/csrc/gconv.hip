@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[AP], rb[BP];
+  f32x4 ra[AP], rb[BP];     // staging registers of the tile being fetched (fast path: the even tiles)
+  f32x4 ra1[AP], rb1[BP];   // fast path: the odd tiles -- two k-tiles of gathers are in flight
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = ra[i];
@@ -259,31 +260,46 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
       cx.bit = live ? (unsigned)ti.z : 0u;
       return cx;
     };
-    auto load_a = [&](const Ctx& cx, int i) {
+    auto load_a = [&](const Ctx& cx, int i, auto SET) {
       const unsigned off = (amask[i] & cx.bit) ? aoffB[i] + (unsigned)cx.doff : OOB;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0));
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0));
+      if (decltype(SET)::value) ra1[i] = v; else ra[i] = v;
     };
-    auto load_b = [&](const Ctx& cx, int j) {
+    auto load_b = [&](const Ctx& cx, int j, auto SET) {
       // an invalid row / dead tile keeps the offset out of range (weights are < 2 GiB, checked on the host)
       const unsigned off = (woffB[j] | (unsigned)cx.woff) >= OOB ? OOB : woffB[j] + (unsigned)cx.woff;
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0));
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0));
+      if (decltype(SET)::value) rb1[j] = v; else rb[j] = v;
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
     if (qb < qe) {
+      // Software pipeline, two k-tiles deep: while tile q is multiplied out of LDS, tile q+1 (gathers issued one
+      // iteration ago) is written to the other LDS buffer and the gathers of tile q+2 are issued.  A lone block on
+      // a CU (small layers, split-K tails) has ~1.5 iterations to cover the memory latency instead of ~0.5.
       int q = qb;
       int li = q / cpt, ch = q - li * cpt;
       {
         const Ctx c0 = tile_ctx(li, ch, true);
 #pragma unroll
-        for (int i = 0; i < AP; ++i) load_a(c0, i);
+        for (int i = 0; i < AP; ++i) load_a(c0, i, Set0{});
 #pragma unroll
-        for (int j = 0; j < BP; ++j) load_b(c0, j);
+        for (int j = 0; j < BP; ++j) load_b(c0, j, Set0{});
+        if (++ch == cpt) { ch = 0; ++li; }
+        const Ctx c1 = tile_ctx(li, ch, q + 1 < qe);
+#pragma unroll
+        for (int i = 0; i < AP; ++i) load_a(c1, i, Set1{});
+#pragma unroll
+        for (int j = 0; j < BP; ++j) load_b(c1, j, Set1{});
       }
       store_tile(0);
       if (++ch == cpt) { ch = 0; ++li; }
-      Ctx cxn = tile_ctx(li, ch, q + 1 < qe);
+      Ctx cxn = tile_ctx(li, ch, q + 2 < qe);
       __syncthreads();
       int buf = 0;
-      while (q < qe) {
+      // one iteration; FETCH = staging set that receives tile q+2 (the other one holds tile q+1)
+      auto iteration = [&](auto FETCH) {
+        constexpr int fetch = decltype(FETCH)::value;
         const float* Ac = Ab + buf * (BM * LDK);
         const float* Bc = Bb + buf * (BN * LDK);
         float* Aw = &As[buf ^ 1][r0 * LDK + c4 * 4];
@@ -294,9 +310,9 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDK);
         // One MFMA per slot; behind each, at most one memory instruction:
-        //   first quarter  : the NL global gathers of the next tile
+        //   first quarter  : the NL global gathers of tile q+2
         //   per k-group    : the TM+TN fragment reads of the next k-group
-        //   last quarter   : the NL LDS writes of the next tile (its gathers are >= NMF/2 MFMAs old)
+        //   last quarter   : the NL LDS writes of tile q+1 (its gathers are more than an iteration old)
 #pragma unroll
         for (int s = 0; s < NMF; ++s) {
           const int kg = s / (4 * TM * TN), e = (s / (TM * TN)) & 3, i = (s / TN) % TM, j = s % TN;
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
 #pragma unroll
               for (int x = 0; x < NL; ++x) {
                 if ((x * Q) / NL != s) continue;
-                if (x < AP) load_a(cxn, x); else load_b(cxn, x - AP);
+                if (x < AP) load_a(cxn, x, FETCH); else load_b(cxn, x - AP, FETCH);
               }
             }
           }
@@ -321,9 +337,9 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
                 fb[(kg + 1) & 1][sg - TM] = *reinterpret_cast<const f32x4*>(Bc + (sg - TM) * 32 * LDK + (kg + 1) * 8);
             }
           }
-          if (s == NMF / 2) {  // constants of the tile after next (LDS broadcast read, consumed next iteration)
+          if (s == NMF / 2) {  // constants of the tile fetched by the next iteration (LDS broadcast read)
             if (++ch == cpt) { ch = 0; ++li; }
-            cxn2 = tile_ctx(li, ch, q + 2 < qe);
+            cxn2 = tile_ctx(li, ch, q + 3 < qe);
           }
           {  // LDS writes over the last quarter
             constexpr int Q = NMF / 4;
@@ -332,8 +348,8 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
 #pragma unroll
               for (int x = 0; x < NL; ++x) {
                 if ((x * Q) / NL != sw) continue;
-                if (x < AP) *reinterpret_cast<f32x4*>(Aw + 32 * x * LDK) = ra[x];
-                else *reinterpret_cast<f32x4*>(Bw + 32 * (x - AP) * LDK) = rb[x - AP];
+                if (x < AP) *reinterpret_cast<f32x4*>(Aw + 32 * x * LDK) = fetch ? ra[x] : ra1[x];
+                else *reinterpret_cast<f32x4*>(Bw + 32 * (x - AP) * LDK) = fetch ? rb[x - AP] : rb1[x - AP];
               }
             }
           }
@@ -343,6 +359,11 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
         __syncthreads();
         buf ^= 1;
         ++q;
+      };
+      while (q < qe) {
+        iteration(Set0{});        // tile q+2 -> set 0 (q - qb even), tile q+1 sits in set 1
+        if (q >= qe) break;
+        iteration(Set1{});
       }
     }
   } else {
@@ -518,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     __syncthreads();
     if (!s_last) return;
     // all 16 rows x 4 slabs of a sub-tile are requested before the first one is consumed (the loads bypass L2:
-    // one memory latency per 4 slabs instead of one per slab).  Buffer loads: 32-bit offsets, out-of-range -> 0.
+    // one memory latency per 4 slabs instead of one per slab).  Buffer loads: 32-bit offsets, invalid rows -> 0.
     const __amdgpu_buffer_rsrc_t rws =
         __builtin_amdgcn_make_buffer_rsrc((void*)d.ws, 0, (unsigned)(d.splitk * d.out_elems * 4), 0x00020000);
     constexpr int kSc1 = 16;          // cache policy: device scope
@@ -537,12 +558,13 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = 0.f;
-        for (int sl0 = 0; sl0 < d.splitk; sl0 += 4) {
+        // (the bounds check of a buffer load covers voffset only: every soffset used here is a real slab)
+        int sl0 = 0;
+        for (; sl0 + 4 <= d.splitk; sl0 += 4) {
           float tmp[4][16];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            // slabs past the last one: soffset beyond num_records -> 0
-            const unsigned soff = (sl0 + u < d.splitk) ? (unsigned)(sl0 + u) * slab_bytes : 0xFFFFFF00u;
+            const unsigned soff = (unsigned)(sl0 + u) * slab_bytes;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               tmp[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, (int)voff[r], (int)soff, kSc1));
@@ -551,6 +573,15 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
           for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += tmp[u][r];
+        }
+        for (; sl0 < d.splitk; ++sl0) {
+          const unsigned soff = (unsigned)sl0 * slab_bytes;
+          float tmp[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tmp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, (int)voff[r], (int)soff, kSc1));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += tmp[r];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = v[r];
@@ -581,7 +612,7 @@ static TileCfg pick_tile(long long M, int N) {
   return best;
 }
 
-static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec) {
+static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec, bool dense_k) {
   long long Mtot = 0;
   int max_taps = 0;
   for (int i = 0; i < d.nphase; ++i) {
@@ -617,10 +648,23 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   }
   d.in_bytes = (unsigned)(in_elems * 4);
   d.w_bytes = (unsigned)(w_elems * 4);
-  // split-K when the grid cannot give every CU two blocks
+  // split-K when the grid cannot give every CU two blocks.  All blocks of such a grid are resident at once, so the
+  // launch lasts as long as the fullest CU: n = ceil(blocks*S / CUs) blocks of nkt/S k-tiles each, a little slower
+  // per block when the CU holds fewer than 4, plus about half a k-tile of slab traffic per slab
+  // (scratch/sweep_splitk.py).  Data-gradient launches skip dead taps tile by tile, so their k-depth is not known
+  // here: they keep the plain "two blocks per CU" rule.
   int S = 1;
   const long long blocks = (long long)tiles * ntile_n;
-  if (blocks < 2 * kNumCU && max_nkt >= 8) {
+  if (blocks < 2 * kNumCU && max_nkt >= 8 && dense_k) {
+    static const double eff[5] = {1.0, 0.82, 0.96, 0.99, 1.0};
+    double best = 1e30;
+    for (int sc = 1; sc <= 8 && max_nkt / sc >= 4; ++sc) {
+      if (sc > 1 && (size_t)sc * d.out_elems * sizeof(float) > ws_payload_bytes(ws_bytes)) break;
+      const long long n = (blocks * sc + kNumCU - 1) / kNumCU;
+      const double cost = (double)n / sc / eff[n < 4 ? n : 4] * max_nkt + (sc > 1 ? 0.5 * sc : 0.0);
+      if (cost < 0.97 * best) { best = cost; S = sc; }
+    }
+  } else if (blocks < 2 * kNumCU && max_nkt >= 8) {
     S = (int)((2 * kNumCU + blocks - 1) / blocks);
     if (S > max_nkt / 4) S = max_nkt / 4;
     if (S > 32) S = 32;
@@ -701,7 +745,7 @@ extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w
   P.nr = g->R; P.ns = g->S;
   for (int r = 0; r < g->R; ++r) { P.dh[r] = (signed char)(r - g->pad); P.wr[r] = (unsigned char)r; }
   for (int s = 0; s < g->S; ++s) { P.dw[s] = (signed char)(s - g->pad); P.ws[s] = (unsigned char)s; }
-  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->C % 4) == 0);
+  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->C % 4) == 0, g->pad == 0);
 }
 
 extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w, float* dx,
@@ -741,5 +785,5 @@ extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const fl
         ++P.ns;
       }
     }
-  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->K % 4) == 0);
+  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->K % 4) == 0, false);
 }

@@ -457,7 +457,14 @@ wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, 
     if (gc < Cg && dc < Cd) {
       const float* src = ws + (long long)(tap * Cg + gc) * Cd + dc;
       int sidx = sg;
-      for (; sidx + 3 * SGN < S; sidx += 4 * SGN) {      // four independent loads in flight, summed in slab order
+      for (; sidx + 7 * SGN < S; sidx += 8 * SGN) {      // eight independent loads in flight, summed in slab order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)(sidx + u * SGN) * total);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      for (; sidx + 3 * SGN < S; sidx += 4 * SGN) {
         const float4 v0 = *reinterpret_cast<const float4*>(src + (long long)sidx * total);
         const float4 v1 = *reinterpret_cast<const float4*>(src + (long long)(sidx + SGN) * total);
         const float4 v2 = *reinterpret_cast<const float4*>(src + (long long)(sidx + 2 * SGN) * total);
@@ -566,21 +573,25 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     const long long total = (long long)d.Mtot * g->K;
     const int T = g->R * g->S;
     if (fast && T <= kRedRows) {
-      // tile: G gathered channels x T taps (>= 16 rows, <= 64) by 32 or 16 dense channels; grow G while the grid stays deep
+      // tile: G gathered channels x T taps (>= 16 rows, <= 64) by TD dense channels.  Reads dominate (S slabs in, one
+      // tile out): take the widest TD that still gives the grid two blocks per CU, and grow G while it stays that deep.
       int G = (16 + T - 1) / T;
       auto nblk = [&](int G_, int TD_) { return (long long)((g->C + G_ - 1) / G_) * ((g->K + TD_ - 1) / TD_); };
       while (2 * G * T <= kRedRows && nblk(2 * G, 32) >= 2 * kNumCU) G *= 2;
-      const int TD = nblk(G, 32) >= kNumCU ? 32 : 16;
+      int TD = 32;
+      while (TD > 4 && nblk(G, TD) < 2 * kNumCU) TD >>= 1;
       int SGN = kRedLds / (G * T);
       if (SGN > kRedGroups) SGN = kRedGroups;
       if (SGN > S) SGN = S;
       dim3 rgrid((g->C + G - 1) / G, (g->K + TD - 1) / TD);
-      if (TD == 32)
-        hipLaunchKernelGGL(wgrad_reduce_tile_kernel<32>, rgrid, dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
-                           Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN);
-      else
-        hipLaunchKernelGGL(wgrad_reduce_tile_kernel<16>, rgrid, dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
-                           Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN);
+#define RLAUNCH(TD_)                                                                                              \
+  hipLaunchKernelGGL(wgrad_reduce_tile_kernel<TD_>, rgrid, dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log, \
+                     Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN)
+      if (TD == 32) RLAUNCH(32);
+      else if (TD == 16) RLAUNCH(16);
+      else if (TD == 8) RLAUNCH(8);
+      else RLAUNCH(4);
+#undef RLAUNCH
     } else {
       int nb = (int)((total + 255) / 256);
       if (nb > 4096) nb = 4096;
