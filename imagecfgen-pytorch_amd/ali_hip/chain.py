@@ -256,8 +256,32 @@ class _Saved:
     __slots__ = ("x_in", "t", "y", "mask", "bn_stats", "bn", "pattern", "geom", "in_shape", "out_shape", "training")
 
 
-def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool):
-    """x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list)."""
+def slice_saved(saved, group: int, groups: int):
+    """The saved state of one of the ``groups`` passes that ``chain_forward(..., groups=...)`` ran as one batch
+    (contiguous row ranges of every activation, that pass's BatchNorm statistics)."""
+    out = []
+    for sv in saved:
+        B = sv.in_shape[0] // groups
+        lo, hi = group * B, (group + 1) * B
+        s2 = _Saved()
+        s2.x_in, s2.t, s2.y = sv.x_in[lo:hi], sv.t[lo:hi], sv.y[lo:hi]
+        s2.mask = None if sv.mask is None else sv.mask[lo:hi]
+        s2.bn, s2.pattern, s2.training = sv.bn, sv.pattern, sv.training
+        s2.bn_stats = None if sv.bn_stats is None else (sv.bn_stats[group] if isinstance(sv.bn_stats, list)
+                                                        else sv.bn_stats)
+        s2.in_shape, s2.out_shape = (B,) + tuple(sv.in_shape[1:]), (B,) + tuple(sv.out_shape[1:])
+        g = sv.geom
+        s2.geom = ops.geom(B, g.H, g.W, g.C, g.P, g.Q, g.K, g.R, g.S, g.stride, g.pad)
+        out.append(s2)
+    return out
+
+
+def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool, groups: int = 1):
+    """x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list).
+
+    ``groups`` > 1: the batch holds that many independent forward passes back to back (equal sample counts).  The
+    convolutions run once over all of them; BatchNorm takes its batch statistics -- and updates the running ones --
+    pass by pass, in order, exactly as separate calls would."""
     saved = []
     cur = x
     c_log = c_log_in
@@ -285,11 +309,27 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             mask_in = mask if kinds == ["drop", "bn"] else None
             mask_post = mask if kinds == ["bn", "drop"] else None
             use_batch = training or bn.running_mean is None
-            st4 = ops.bn_stats(cur, mask_in, B, rows, Cp, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                               bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch)
-            if use_batch and bn.num_batches_tracked is not None:
-                _count_batch(bn)
-            t = ops.bn_apply(cur, st4, mask_in, mask_post, B, rows, Cp)
+            if groups == 1:
+                st4 = ops.bn_stats(cur, mask_in, B, rows, Cp, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                   bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch)
+                if use_batch and bn.num_batches_tracked is not None:
+                    _count_batch(bn)
+                t = ops.bn_apply(cur, st4, mask_in, mask_post, B, rows, Cp)
+            else:
+                Bg = B // groups
+                t = torch.empty_like(cur)
+                st4 = []
+                for gi in range(groups):
+                    lo, hi = gi * Bg, (gi + 1) * Bg
+                    mi = None if mask_in is None else mask_in[lo:hi]
+                    mp = None if mask_post is None else mask_post[lo:hi]
+                    sg = ops.bn_stats(cur[lo:hi], mi, Bg, rows, Cp, bn.weight.detach(), bn.bias.detach(),
+                                      bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+                                      bn.eps, use_batch)
+                    if use_batch and bn.num_batches_tracked is not None:
+                        _count_batch(bn)
+                    ops.bn_apply(cur[lo:hi], sg, mi, mp, Bg, rows, Cp, out=t[lo:hi])
+                    st4.append(sg)
             sv.bn_stats = st4
         elif mask is not None and not mask_applied:
             t = ops.rowmask_mul(cur, mask, B, rows, Cp)
@@ -336,6 +376,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
     gx = None
     for i in range(n - 1, -1, -1):
         st, sv = plan.stages[i], saved[i]
+        assert not isinstance(sv.bn_stats, list), "grouped forward state: backpropagate slice_saved(saved, g, groups)"
         B, H, W, Cp = sv.in_shape
         _, P, Q, K = sv.out_shape
         rows_out = B * P * Q

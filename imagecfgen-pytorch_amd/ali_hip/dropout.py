@@ -13,7 +13,7 @@ import torch
 from . import ops
 
 _state = {"seed": 0x5EED, "offset": 0, "inject": None, "pos": 0, "dev_counter": None,
-          "plan": None, "record": None, "req": 0}
+          "plan": None, "record": None, "req": 0, "pair": 0}
 
 
 def manual_seed(seed: int):
@@ -29,6 +29,20 @@ def injected_masks(masks):
         yield
     finally:
         _state["inject"], _state["pos"] = prev
+
+
+@contextlib.contextmanager
+def paired_passes(n_per_pass: int):
+    """Two forward passes of one stack batched along the sample axis (rows [0,B) = first pass, [B,2B) = second):
+    every mask request inside is for 2B samples.  Replayed (injected) masks were recorded pass after pass, so request
+    k is served by masks k and n_per_pass + k of the tape; generated masks are simply drawn for 2B samples."""
+    prev, _state["pair"] = _state["pair"], int(n_per_pass)
+    try:
+        yield
+    finally:
+        if _state["inject"] is not None and _state["pair"]:
+            _state["pos"] += _state["pair"]          # the second pass's masks were consumed alongside the first's
+        _state["pair"] = prev
 
 
 def begin_iteration(dev_counter, owner=None):
@@ -87,6 +101,10 @@ def next_mask(B: int, C: int, p: float, device, cpad=None) -> torch.Tensor:
         if _state["pos"] >= len(inj):
             raise RuntimeError("injected dropout masks exhausted")
         m = inj[_state["pos"]]
+        if _state["pair"]:
+            if _state["pos"] + _state["pair"] >= len(inj):
+                raise RuntimeError("injected dropout masks exhausted (paired passes)")
+            m = torch.cat([m, inj[_state["pos"] + _state["pair"]]], dim=0)
         _state["pos"] += 1
         if tuple(m.shape) != (B, C):
             raise RuntimeError(f"injected mask shape {tuple(m.shape)} != {(B, C)}")

@@ -28,7 +28,7 @@ from . import dp
 from . import dropout as _dropout
 from . import ops
 from . import chain as _chain
-from .chain import chain_backward, chain_forward, get_plan
+from .chain import chain_backward, chain_forward, get_plan, slice_saved
 
 
 class FlatGroup:
@@ -143,6 +143,8 @@ class AliStepper:
         self.bn_buffers = [b for n_, b in D.named_buffers() if "running" in n_]
         self.iter_t = torch.zeros(1, dtype=torch.int64, device=self.opt_d.flat.device)
         self._emb_planes = tuple(range(1, 1 + len(self.family.d_tables)))
+        self._n_drop = sum(1 for pl in (self.pDx, self.pDz, self.pDxz) for st in pl.stages
+                           if any(k == "drop" for k, _ in st.pre))
 
     # ------------------------------------------------------------------ pieces
     def _planes(self, X, idx, cont, tables):
@@ -175,13 +177,22 @@ class AliStepper:
             feats.append(torch.zeros(B, pad, device=z.device))
         return torch.cat(feats, dim=1).reshape(B, 1, 1, n_log + pad), n_log
 
-    def _d_forward(self, x0, n_log, zin, save):
+    def _d_forward(self, x0, n_log, zin, save, groups=1):
         B = x0.shape[0]
-        dx, s_dx = chain_forward(self.pDx, x0, True, n_log, save)
-        dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save)
+        dx, s_dx = chain_forward(self.pDx, x0, True, n_log, save, groups)
+        dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups)
         joint = torch.cat([dx.reshape(B, -1), dz.reshape(B, -1)], dim=1).reshape(B, 1, 1, -1)
-        logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save)
+        logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups)
         return logit.reshape(B, 1), (s_dx, s_dz, s_dxz, dx.shape[-1], n_log)
+
+    def _d_forward_pair(self, x0a, zina, x0b, zinb, n_log, save):
+        """D(a) and D(b) with the same weights as ONE batch of 2B samples (rows [0,B) = a): half the launches, and
+        the small 1x1 layers see twice the rows.  BatchNorm statistics, running-stat updates and Dropout2d masks stay
+        per pass, in the order a, b (chain_forward groups / dropout.paired_passes)."""
+        B = x0a.shape[0]
+        with _dropout.paired_passes(self._n_drop):
+            logit, saved = self._d_forward(torch.cat([x0a, x0b], dim=0), n_log, torch.cat([zina, zinb], dim=0), save, 2)
+        return logit[:B], logit[B:], saved
 
     def _d_backward(self, saved, glogit, need_params, need_x, need_z, planes=None):
         s_dx, s_dz, s_dxz, n_dx, n_log = saved
@@ -217,21 +228,29 @@ class AliStepper:
         x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
         ex, sE = chain_forward(self.pE, x0e, True, n_log, True)
         x0d, _ = self._planes(images, idx, cont, fam.d_tables)
-        d_valid, sD1 = self._d_forward(x0d, n_log, ex, True)
         gin, g_log = self._g_input(zin, onehots, cont)
         gz, sG = chain_forward(self.pG, gin, True, g_log, True)
         x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
-        d_fake, sD2 = self._d_forward(x0f, n_log, zin, True)
-        l1, gl1 = ops.bce_logits(d_valid, 0.0, 0.5)
-        l2, gl2 = ops.bce_logits(d_fake, 1.0, 0.5)
+        # D(x, E(x)) and D(G(z), z) share the weights: one batch of 2B samples (reference order: real pass first)
+        d_valid, d_fake, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(x0d, ex.reshape(zin.shape), x0f, zin,
+                                                                             n_log, True)
+        l1, gl1 = ops.bce_logits(d_valid.contiguous(), 0.0, 0.5)
+        l2, gl2 = ops.bce_logits(d_fake.contiguous(), 1.0, 0.5)
         cx["out"]["loss_eg"] = (l1[0] + l2[0]) / 2
-        # real branch: only the z-side path (dxz -> dz) reaches E
-        _, g_ex = self._d_backward(sD1, gl1, False, False, True)
+        # backward: dxz for both passes at once (data gradient only: D is not updated in this phase) ...
+        gjoint, _ = chain_backward(self.pDxz, s_dxz, torch.cat([gl1, gl2], dim=0).reshape(2 * B, 1, 1, 1),
+                                   s_dxz[0].in_shape[3], True, False)
+        gjoint = gjoint.reshape(2 * B, -1)
         dst = self.opt_eg.grad_views
+        # ... real pass: only the z-side path (dxz -> dz) reaches E
+        nz = gjoint.shape[1] - n_dx
+        g_ex, _ = chain_backward(self.pDz, slice_saved(s_dz, 0, 2), gjoint[:B, n_dx:].contiguous().reshape(B, 1, 1, nz),
+                                 nz, True, False)
         g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, True, True, dst)
         self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
-        # fake branch: only the image path (dxz -> dx) reaches G
-        g_x0f, _ = self._d_backward(sD2, gl2, False, True, False, planes=(0,))
+        # ... fake pass: only the image path (dxz -> dx) reaches G
+        g_x0f, _ = chain_backward(self.pDx, slice_saved(s_dx, 1, 2), gjoint[B:, :n_dx].contiguous().reshape(B, 1, 1, n_dx),
+                                  n_log, True, False, gx_planes=(0,))
         g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
         g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst)
         g_gin = g_gin.reshape(B, -1)
@@ -299,11 +318,10 @@ class AliStepper:
         re-using G'(z) and E'(x) of the D phases (the reference recomputes identical values)."""
         fam, images, idx, cont, zin = self.family, cx["images"], cx["idx"], cx["cont"], cx["zin"]
         x0f, _ = self._planes(cx["gz"], idx, cont, fam.d_tables)
-        dg, _ = self._d_forward(x0f, cx["n_log"], zin, False)
         x0d, _ = self._planes(images, idx, cont, fam.d_tables)
-        de, _ = self._d_forward(x0d, cx["n_log"], cx["ex"], False)
-        cx["out"]["dg"] = ops.bce_logits(dg, 0.0, 1.0, want_grad=False)[0][1]
-        cx["out"]["de"] = ops.bce_logits(de, 0.0, 1.0, want_grad=False)[0][1]
+        dg, de, _ = self._d_forward_pair(x0f, zin, x0d, cx["ex"].reshape(zin.shape), cx["n_log"], False)
+        cx["out"]["dg"] = ops.bce_logits(dg.contiguous(), 0.0, 1.0, want_grad=False)[0][1]
+        cx["out"]["de"] = ops.bce_logits(de.contiguous(), 0.0, 1.0, want_grad=False)[0][1]
         _dropout.end_iteration()
         _chain.flush_batch_counts()        # all BatchNorm num_batches_tracked increments of the iteration: one launch
         if self.world > 1 and average_bn:
