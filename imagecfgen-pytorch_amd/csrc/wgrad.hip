@@ -535,8 +535,10 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   const long long blocks = (long long)tiles_m * tiles_n;
   int S = 1;
   const int nkt = (d.npix + wbk - 1) / wbk;
-  if (blocks < 4 * kNumCU && nkt >= 4) {
-    S = (int)((4 * kNumCU + blocks - 1) / blocks);
+  int target = 4 * kNumCU;
+  { const char* e = getenv("ALI_WGRAD_BLOCKS"); if (e && atoi(e) > 0) target = atoi(e); }
+  if (blocks < target && nkt >= 4) {
+    S = (int)((target + blocks - 1) / blocks);
     if (S > nkt / 2) S = nkt / 2;
     if (S > 128) S = 128;
     while (S > 1 && (size_t)S * ((size_t)d.Mtot + 1) * g->K * sizeof(float) > ws_bytes) --S;
