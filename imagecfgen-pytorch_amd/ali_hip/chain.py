@@ -118,8 +118,9 @@ class ChainPlan:
         return out
 
     # ------------------------------------------------------------------ packing
-    def packed(self, st: Stage, which: str, cin_stride: int):
-        """which = 'fwd' | 'dgrad' kernel-layout weights of a stage (see include/ali_hip.h)."""
+    def packed(self, st: Stage, which, cin_stride: int):
+        """which = 'fwd' | 'dgrad' kernel-layout weights of a stage (see include/ali_hip.h); 'scatter' and
+        ('scatter_dgrad', planes): the 1x1 GEMM weights of the scatter-form transposed convolutions (ali_col2im)."""
         w = st.mod.weight
         dev = w.device
 
@@ -128,6 +129,17 @@ class ChainPlan:
                 if dst is not None:
                     return dst.reshape(shape)
                 return (torch.zeros if zero else torch.empty)(*shape, device=dev)
+            if which == "scatter":            # ConvT [Ci][Co][R][S] -> rows n = tap*Co + co, columns ci
+                Ci, Co, R, S = w.shape
+                out = buf(R * S * Co, 1, cin_stride, zero=True)
+                out[:, 0, :Ci].copy_(w.detach().permute(2, 3, 1, 0).reshape(R * S * Co, Ci))
+                return out
+            if isinstance(which, tuple) and which[0] == "scatter_dgrad":   # Conv [K][C][R][S] -> rows tap*NP + j, cols k
+                K, C, R, S = w.shape
+                sel = torch.stack([w.detach()[:, c] for c in which[1]], dim=0)          # [NP][K][R][S], slices only
+                out = buf(R * S * len(which[1]), 1, K)
+                out[:, 0, :].copy_(sel.permute(2, 3, 0, 1).reshape(R * S * len(which[1]), K))
+                return out
             if st.kind == "conv":
                 K, C, R, S = w.shape
                 T = R * S
@@ -209,6 +221,24 @@ def _is_tconv1(st: Stage, cin_stride: int) -> bool:
     m = st.mod
     return (st.kind == "convT" and m.out_channels == 1 and m.stride[0] == 1 and m.output_padding[0] == 0
             and m.kernel_size[0] <= 5 and cin_stride in (32, 64, 128, 256) and st.act in (ACT_NONE, ACT_LEAKY, ACT_TANH))
+
+
+def _scatter_fwd(st: Stage, cin_stride: int) -> bool:
+    """ConvTranspose2d with one or two output channels that the direct kernels do not cover (stride 2 Generator tails of
+    the spectrogram models): per-input-pixel tap contributions by a 1x1 GEMM with N = Cout*R*S columns, then
+    ali_col2im -- an implicit GEMM over the output pixels would use 1/32 of every MFMA tile."""
+    m = st.mod
+    return (st.kind == "convT" and m.out_channels <= 2 and m.out_channels * m.kernel_size[0] * m.kernel_size[1] <= 64
+            and cin_stride % 4 == 0 and not _is_tconv1(st, cin_stride))
+
+
+def _scatter_dgrad(st: Stage, planes) -> bool:
+    """The few consumed input planes of a first Conv2d's data gradient, same scatter form.  The contribution tensor
+    (planes * taps floats per pixel, written and read once) makes it HBM bound: measured break-even with the implicit
+    GEMM at about 6 planes of a 5x5 filter, a clear win below."""
+    m = st.mod
+    return (st.kind == "conv" and planes is not None and 1 <= len(planes) <= 8 and m.out_channels % 4 == 0
+            and len(planes) * m.kernel_size[0] * m.kernel_size[1] <= 128)
 
 
 def _first_conv_direct(st: Stage, c_in_log: int) -> bool:
@@ -348,6 +378,15 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             m = st.mod
             ops.tconv1_fwd(t, plan.packed(st, "fwd", Cp), plan.packed_bias(st), y, B, H, W, Cp, m.kernel_size[0],
                            m.kernel_size[1], m.padding[0], 1, st.act, st.slope)
+        elif _scatter_fwd(st, Cp) and folded is None:
+            m = st.mod
+            R, S = m.kernel_size
+            Co = m.out_channels
+            contrib = torch.empty(B, H, W, Co * R * S, dtype=torch.float32, device=cur.device)
+            ops.conv_fwd(ops.geom(B, H, W, Cp, H, W, Co * R * S, 1, 1, 1, 0), t, plan.packed(st, "scatter", Cp), contrib,
+                         ops.epilogue())
+            ops.col2im(contrib, Co * R * S, plan.packed_bias(st), y, B, H, W, out_shape[1], out_shape[2], Co, Co, R, S,
+                       m.stride[0], m.padding[0], st.act, st.slope)
         elif st.kind == "convT":
             ops.conv_bwd_data(g, t, plan.packed(st, "fwd", Cp), y, ep)
         else:
@@ -440,6 +479,19 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                                m.padding[0], len(gx_planes), ACT_NONE, 0.0)
             if sv.mask is not None:
                 cols = torch.cat([sv.mask[:, c:c + 1] for c in gx_planes], dim=1)   # slices only: graph-capture safe
+                planes = planes * cols.reshape(B, 1, 1, -1)
+            gx = planes
+            break
+        if i == 0 and sv.bn is None and _scatter_dgrad(st, gx_planes):
+            R, S = m.kernel_size
+            NP = len(gx_planes)
+            contrib = torch.empty(B, P, Q, NP * R * S, dtype=torch.float32, device=gy.device)
+            ops.conv_fwd(ops.geom(B, P, Q, K, P, Q, NP * R * S, 1, 1, 1, 0), g_pre,
+                         plan.packed(st, ("scatter_dgrad", tuple(gx_planes)), Cp), contrib, ops.epilogue())
+            planes = torch.empty(B, H, W, NP, dtype=torch.float32, device=gy.device)
+            ops.col2im(contrib, NP * R * S, None, planes, B, P, Q, H, W, NP, NP, R, S, m.stride[0], m.padding[0])
+            if sv.mask is not None:
+                cols = torch.cat([sv.mask[:, c:c + 1] for c in gx_planes], dim=1)
                 planes = planes * cols.reshape(B, 1, 1, -1)
             gx = planes
             break

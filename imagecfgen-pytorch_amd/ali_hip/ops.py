@@ -328,6 +328,14 @@ def bn_bwd(x, g, mask_in, mask_pre, st, gamma, B, rows_per_img, C, batch_stats, 
     return out_dgamma, out_dbeta, gx
 
 
+def col2im(contrib, ldc, bias, out, B, H, W, Hout, Wout, NC, ostride, R, S, stride, pad, act=ACT_NONE, slope=0.0):
+    """Gather half of a scatter-form transposed convolution (include/ali_hip.h: ali_col2im)."""
+    lib = _lib.load()
+    _lib.check(lib.ali_col2im(_chk(contrib, "contrib"), ldc, _opt(bias, "bias"), _chk(out, "out"), B, H, W, Hout, Wout,
+                              NC, ostride, R, S, stride, pad, act, float(slope), _stream()), "ali_col2im")
+    return out
+
+
 def bce_logits(logit, target, gscale=1.0, want_grad=True):
     """returns (out2 = [loss, mean sigmoid] device tensor, glogit or None)."""
     lib = _lib.load()

@@ -246,8 +246,11 @@ class AliStepper:
         nz = gjoint.shape[1] - n_dx
         g_ex, _ = chain_backward(self.pDz, slice_saved(s_dz, 0, 2), gjoint[:B, n_dx:].contiguous().reshape(B, 1, 1, nz),
                                  nz, True, False)
-        g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, True, True, dst)
-        self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
+        # of E's input gradient only the embedding planes are consumed (their tables are parameters of E)
+        g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, bool(self._emb_planes), True, dst,
+                                  gx_planes=self._emb_planes or None)
+        if self._emb_planes:
+            self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
         # ... fake pass: only the image path (dxz -> dx) reaches G
         g_x0f, _ = chain_backward(self.pDx, slice_saved(s_dx, 1, 2), gjoint[B:, :n_dx].contiguous().reshape(B, 1, 1, n_dx),
                                   n_log, True, False, gx_planes=(0,))
@@ -544,11 +547,14 @@ class FinetuneStepper:
         g_gin, _ = chain_backward(self.pG, sG, g_xr, g_log, True, need_params=False)
         g_codes = (g_gin.reshape(B, -1)[:, :zin.shape[1]] + zin * (2.0 / zin.numel())).contiguous()
         dst = self.opt_e.grad_views
-        g_x0, _ = chain_backward(self.pE, sE, g_codes.reshape(codes.shape), n_log, True, True, dst)
+        emb = tuple(range(1, 1 + len(fam.e_tables)))       # only these planes of E's input gradient are consumed
+        g_x0, _ = chain_backward(self.pE, sE, g_codes.reshape(codes.shape), n_log, bool(emb), True, dst,
+                                 gx_planes=emb or None)
+        gofs = 0 if (g_x0 is not None and g_x0.shape[-1] == len(emb)) else 1
         from .planes import plane_to_table_grad
         for j, t in enumerate(fam.e_tables):
             plane = x0[..., 1 + j].reshape(B, H * W)
-            gp = g_x0[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)
+            gp = g_x0[..., gofs + j].reshape(B, H * W) * (1 - plane * plane)
             dst[id(t)].copy_(plane_to_table_grad(gp, idx[:, j], t.shape[0], H, W))
         self.opt_e.adam()
         self.pE.cache.refresh()

@@ -486,6 +486,39 @@ static int reduce_blocks_vec(long long rows, int C) {
   return (int)nb;
 }
 
+// ---- col2im for transposed convolutions in scatter form (see ali_hip.h): one thread per output pixel, NC channels
+template <int NC>
+__global__ void __launch_bounds__(kEwBlock)
+col2im_kernel(const float* __restrict__ contrib, int ldc, const float* __restrict__ bias, float* __restrict__ out,
+              int B, int H, int W, int Hout, int Wout, int ostride, int R, int S, int stride, int pad, int act,
+              float slope) {
+  const long long total = (long long)B * Hout * Wout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wout);
+    const long long t2 = i / Wout;
+    const int oy = (int)(t2 % Hout), b = (int)(t2 / Hout);
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = bias ? bias[c] : 0.f;
+    // taps r = r0, r0 + stride, ... are the ones with (oy + pad - r) divisible by stride
+    const int r0 = (oy + pad) % stride, s0 = (ox + pad) % stride;
+    for (int r = r0; r < R; r += stride) {
+      const int ih = (oy + pad - r) / stride;
+      if (oy + pad - r < 0 || ih >= H) continue;
+      for (int s = s0; s < S; s += stride) {
+        const int iw = (ox + pad - s) / stride;
+        if (ox + pad - s < 0 || iw >= W) continue;
+        const float* src = contrib + ((long long)(b * H + ih) * W + iw) * ldc + (r * S + s) * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] += src[c];
+      }
+    }
+    float* o = out + i * ostride;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o[c] = apply_act(acc[c], act, slope);
+  }
+}
+
 // ---- BCE with logits against a constant target (single block; B <= a few thousand)
 __global__ void bce_logits_kernel(const float* __restrict__ logit, int B, float target, float gscale,
                                   float* __restrict__ out2, float* __restrict__ glogit) {
@@ -758,6 +791,33 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
                          lrelu_slope, gx);
   }
   return check_launch("bn_bwd");
+}
+
+extern "C" int ali_col2im(const float* contrib, int32_t ldc, const float* bias, float* out, int32_t B, int32_t H,
+                          int32_t W, int32_t Hout, int32_t Wout, int32_t NC, int32_t ostride, int32_t R, int32_t S,
+                          int32_t stride, int32_t pad, int32_t act, float slope, ali_stream_t stream) {
+  if (!contrib || !out || B <= 0 || H <= 0 || W <= 0 || Hout <= 0 || Wout <= 0 || NC < 1 || NC > 8 || ostride < NC ||
+      R <= 0 || S <= 0 || stride <= 0 || pad < 0 || ldc < NC * R * S) {
+    set_error("ali_col2im: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  const long long total = (long long)B * Hout * Wout;
+  const dim3 grid(ew_grid(total)), block(kEwBlock);
+#define C2I(NC_)                                                                                                      \
+  hipLaunchKernelGGL(col2im_kernel<NC_>, grid, block, 0, ST(stream), contrib, ldc, bias, out, B, H, W, Hout, Wout, ostride, \
+                     R, S, stride, pad, act, slope)
+  switch (NC) {
+    case 1: C2I(1); break;
+    case 2: C2I(2); break;
+    case 3: C2I(3); break;
+    case 4: C2I(4); break;
+    case 5: C2I(5); break;
+    case 6: C2I(6); break;
+    case 7: C2I(7); break;
+    default: C2I(8); break;
+  }
+#undef C2I
+  return check_launch("col2im_kernel");
 }
 
 extern "C" int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, float* out2, float* glogit,

@@ -186,6 +186,17 @@ int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* 
                         const float* cont, int32_t n_cont, float* out, int32_t B, int32_t H, int32_t W,
                         int32_t Cpad, ali_stream_t stream);
 
+/* Gather half of a strided transposed convolution in scatter form (ConvTranspose2d forward with one or two output
+ * channels -- audio_mnist.py:281, whalecalls.py / esrf_acoustic.py Generator tails -- and the few input planes of a
+ * first Conv2d's data gradient that are consumed, audio_mnist.py:203-210): a 1x1 GEMM (ali_conv_fwd) first produces,
+ * for every pixel (b,h,w) of the H x W map, the contribution contrib[(b,h,w)*ldc + (r*S+s)*NC + c] of that pixel to
+ * output channel c through tap (r,s); this sums, per output pixel, the taps whose source position exists:
+ *   out[((b*Hout+oy)*Wout+ox)*ostride + c] = act(bias[c] + sum_{r,s} contrib[b,(oy+pad-r)/stride,(ox+pad-s)/stride,c,r,s])
+ * over the (r,s) for which both quotients are exact and inside the map.  NC <= 8. */
+int ali_col2im(const float* contrib, int32_t ldc, const float* bias, float* out, int32_t B, int32_t H, int32_t W,
+               int32_t Hout, int32_t Wout, int32_t NC, int32_t ostride, int32_t R, int32_t S, int32_t stride,
+               int32_t pad, int32_t act, float slope, ali_stream_t stream);
+
 const char* ali_last_error(void);
 int ali_version(void);
 

@@ -234,6 +234,24 @@ def test_bce_adam_colsum_dropout():
     assert not torch.equal(mk, ops.dropout_mask(7, 4096 * 64, 0.2, 4096, 64, torch.device("cuda")))
 
 
+@pytest.mark.parametrize("Co,stride,pad,opad,R", [(1, 2, 2, 1, 5), (2, 2, 1, 0, 4), (1, 1, 0, 0, 3), (3, 2, 1, 1, 5), (7, 2, 1, 0, 5)])
+def test_col2im_gathers_scatter_form_transposed_conv(Co, stride, pad, opad, R):
+    """ali_col2im over per-pixel tap contributions == F.conv_transpose2d (the 1x1 GEMM that produces the contributions is
+    the ordinary ali_conv_fwd, covered above; here it is an einsum)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Ci = 3, 9, 7, 16
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Ci, Co, R, R, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    ref = torch.tanh(F.conv_transpose2d(x, w, b, stride=stride, padding=pad, output_padding=opad))
+    contrib = torch.einsum("bchw,cot->bhwto", x, w.reshape(Ci, Co, R * R)).reshape(B, H, W, Co * R * R).contiguous()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.empty(B, Ho, Wo, Co, device="cuda")
+    ops.col2im(contrib.cuda(), Co * R * R, b.cuda(), out, B, H, W, Ho, Wo, Co, Co, R, R, stride, pad, ops.ACT_TANH, 0.0)
+    close(nchw(out), ref, rtol=1e-5, what="col2im")
+
+
 def test_assemble_planes_matches_torch_modules():
     ops = _ops()
     g = torch.Generator().manual_seed(2)
