@@ -525,7 +525,11 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (fast) {
     // more, smaller tiles while the grid is shallow (see gconv.hip: waits are only hidden by co-resident waves)
     const long long b64 = (long long)((d.Mtot + 63) / 64) * ((g->K + 63) / 64);
-    if (g->K > 32 && b64 <= 2 * kNumCU) { bm = 64; bn = 64; }
+    // ... but a long pixel reduction (spectrogram layers) re-reads both operands once per tile pair: larger tiles,
+    // the grid depth comes from the split over pixels
+    long long small_lim = d.npix >= 200000 ? 16 : 2 * kNumCU;
+    { const char* e = getenv("ALI_WGRAD_SMALL"); if (e) small_lim = atoll(e); }
+    if (g->K > 32 && b64 <= small_lim) { bm = 64; bn = 64; }
     else if (g->K > 64) { bm = 128; bn = 128; }
     else if (g->K > 32) { bm = 128; bn = 64; }
     else { bm = 128; bn = 32; }
