@@ -63,31 +63,32 @@ def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=AC
 
 
 class KernelProfile:
-    """Live per-launch timing of the GEMM kernels with HIP events on the launch stream
-    (bench.py's roofline leg).  Each record: (family, algorithmic flops, start event, end event)."""
+    """Live per-launch timing of the GEMM kernels with HIP events on the launch stream (bench.py's roofline leg).
+    Each record: (family, algorithmic flops, (e0, e1, e2), shape); see ``_launch`` for what the events bracket."""
 
     def __init__(self):
         self.records = []
 
-    def summary(self):
-        torch.cuda.synchronize()
-        fam = {}
-        for name, flops, e0, e1, _ in self.records:
-            f = fam.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
-            f["launches"] += 1
-            f["flops"] += flops
-            f["ms"] += e0.elapsed_time(e1)
-        return fam
+    @staticmethod
+    def _ms(ev):
+        e0, e1, e2 = ev
+        return max(e1.elapsed_time(e2) - e0.elapsed_time(e1), 1e-4)
 
-    def by_shape(self):
+    def _table(self, key):
         torch.cuda.synchronize()
         tab = {}
-        for name, flops, e0, e1, desc in self.records:
-            f = tab.setdefault((name,) + desc, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for name, flops, ev, desc in self.records:
+            f = tab.setdefault(key(name, desc), {"launches": 0, "flops": 0.0, "ms": 0.0})
             f["launches"] += 1
             f["flops"] += flops
-            f["ms"] += e0.elapsed_time(e1)
+            f["ms"] += self._ms(ev)
         return tab
+
+    def summary(self):
+        return self._table(lambda name, desc: name)
+
+    def by_shape(self):
+        return self._table(lambda name, desc: (name,) + desc)
 
 
 _PROFILE = None
@@ -98,55 +99,46 @@ def set_profile(p):
     _PROFILE = p
 
 
-class _Timed:
-    def __init__(self, name, g: AliConvGeom):
-        self.name = name
-        self.flops = 2.0 * g.B * g.P * g.Q * g.K * g.C * g.R * g.S
-        self.desc = (g.B, g.H, g.W, g.C, g.P, g.Q, g.K, g.R, g.stride, g.pad)
-
-    def __enter__(self):
-        if _PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-
-    def __exit__(self, *exc):
-        if _PROFILE is not None:
-            self.e1.record()
-            _PROFILE.records.append((self.name, self.flops, self.e0, self.e1, self.desc))
+def _geom_cost(g: AliConvGeom):
+    return (2.0 * g.B * g.P * g.Q * g.K * g.C * g.R * g.S,
+            (g.B, g.H, g.W, g.C, g.P, g.Q, g.K, g.R, g.stride, g.pad))
 
 
-class _TimedRaw:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
-
-    def __enter__(self):
-        if _PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-
-    def __exit__(self, *exc):
-        if _PROFILE is not None:
-            self.e1.record()
-            _PROFILE.records.append((self.name, self.flops, self.e0, self.e1, (0,) * 10))
+def _launch(name, flops, desc, fn):
+    """Run one kernel launch.  Under a KernelProfile it is issued three times between three event records,
+    [e0] fn [e1] fn fn [e2]: both intervals carry the same event-marker latency, so (e2 - e1) - (e1 - e0) is the
+    duration of one launch as it runs back to back with its neighbours (every launch on this path is idempotent)."""
+    if _PROFILE is None:
+        return fn()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    fn()
+    e1.record()
+    fn()
+    fn()
+    e2.record()
+    _PROFILE.records.append((name, flops, (e0, e1, e2), desc))
 
 
 def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
     lib = _lib.load()
     ws = workspace(x.device)
-    with _Timed("gconv", g):
+
+    def go():
         _lib.check(lib.ali_conv_fwd(byref(g), _chk(x, "x"), _chk(w_packed, "w"), _chk(y, "y"), byref(ep),
                                     c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
+    _launch("gconv", *_geom_cost(g), go)
     return y
 
 
 def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
     lib = _lib.load()
     ws = workspace(dy.device)
-    with _Timed("gconv_t", g):
+
+    def go():
         _lib.check(lib.ali_conv_bwd_data(byref(g), _chk(dy, "dy"), _chk(w_packed, "w"), _chk(dx, "dx"), byref(ep),
                                          c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
+    _launch("gconv_t", *_geom_cost(g), go)
     return dx
 
 
@@ -154,10 +146,12 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
     """``db`` (optional, [cd_log]): also produce the column sums of ``dy`` (Conv2d bias gradient) in the same launch."""
     lib = _lib.load()
     ws = workspace(x.device)
-    with _Timed("wgrad", g):
+
+    def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
                                            s_dc, s_gc, s_tap, _opt(db, "db"), c_void_p(ws.data_ptr()), ws.numel(),
                                            _stream()), "ali_conv_bwd_weight")
+    _launch("wgrad", *_geom_cost(g), go)
     return dst
 
 
@@ -170,28 +164,34 @@ def _ptr(t):
 
 def tconv1_fwd(big, w_tk, bias, out, B, P, Q, K, R, S, pad, ostride, act, slope):
     lib = _lib.load()
-    with _TimedRaw("tconv1_fwd", 2.0 * B * P * Q * K * R * S):
+
+    def go():
         _lib.check(lib.ali_tconv1_fwd(_chk(big, "big"), _chk(w_tk, "w"), None if bias is None else _ptr(bias),
                                       _ptr(out), B, P, Q, K, R, S, pad, ostride, act, slope, _stream()),
                    "ali_tconv1_fwd")
+    _launch("tconv1_fwd", 2.0 * B * P * Q * K * R * S, (0,) * 10, go)
     return out
 
 
 def tconv1_dgrad(small, sstride, w_tk, dact_y, dact, dslope, gbig, B, P, Q, K, R, S, pad):
     lib = _lib.load()
-    with _TimedRaw("tconv1_dgrad", 2.0 * B * P * Q * K * R * S):
+
+    def go():
         _lib.check(lib.ali_tconv1_dgrad(_ptr(small), sstride, _chk(w_tk, "w"), _opt(dact_y), dact, dslope,
                                         _chk(gbig, "gbig"), B, P, Q, K, R, S, pad, _stream()), "ali_tconv1_dgrad")
+    _launch("tconv1_dgrad", 2.0 * B * P * Q * K * R * S, (0,) * 10, go)
     return gbig
 
 
 def tconv1_wgrad(big, small, sstride, nc, dw, s_k, s_tap, s_c, B, P, Q, K, R, S, pad):
     lib = _lib.load()
     ws = workspace(big.device)
-    with _TimedRaw("tconv1_wgrad", 2.0 * B * P * Q * K * R * S * nc):
+
+    def go():
         _lib.check(lib.ali_tconv1_wgrad(_chk(big, "big"), _ptr(small), sstride, nc, _ptr(dw), s_k, s_tap, s_c, B, P,
                                         Q, K, R, S, pad, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
                    "ali_tconv1_wgrad")
+    _launch("tconv1_wgrad", 2.0 * B * P * Q * K * R * S * nc, (0,) * 10, go)
     return dw
 
 
