@@ -23,6 +23,12 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def allreduce_sum_async_(flat: torch.Tensor, group=None):
+    """Start the in-place sum of one flat buffer and return the work handle (``.wait()`` orders the caller's stream --
+    or, with gloo, the host -- after it); whatever is launched before the wait overlaps with the collective."""
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def average_buffers_(buffers, group=None):
     """Average a list of small tensors (BatchNorm running stats) with a single collective."""
     w = world_size(group)

@@ -177,9 +177,9 @@ class AliStepper:
             feats.append(torch.zeros(B, pad, device=z.device))
         return torch.cat(feats, dim=1).reshape(B, 1, 1, n_log + pad), n_log
 
-    def _d_forward(self, x0, n_log, zin, save, groups=1):
+    def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None):
         B = x0.shape[0]
-        dx, s_dx = chain_forward(self.pDx, x0, True, n_log, save, groups)
+        dx, s_dx = dx_pre if dx_pre is not None else chain_forward(self.pDx, x0, True, n_log, save, groups)
         dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups)
         joint = torch.cat([dx.reshape(B, -1), dz.reshape(B, -1)], dim=1).reshape(B, 1, 1, -1)
         logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups)
@@ -279,42 +279,56 @@ class AliStepper:
         self._apply_eg()
 
     def _phase_d_real(self, cx):
-        self._d_real_grads(cx)
+        self._d_real_pre(cx)
+        self._d_real_rest(cx)
         if self.world > 1:
             dp.allreduce_sum_(self.opt_d.grad, self.pg)
         self._apply_d()
 
     def _phase_d_fake(self, cx):
-        self._d_fake_grads(cx)
+        self._d_fake_pre(cx)
+        self._d_fake_rest(cx)
         if self.world > 1:
             dp.allreduce_sum_(self.opt_d.grad, self.pg)
         self._apply_d()
 
-    def _d_real_grads(self, cx):
+    # The two D phases are cut where their first dependence on the previous optimiser step sits, so that the
+    # data-parallel all-reduce of that step's gradients overlaps with the part in front of the cut:
+    # D.dx(x) needs neither E' nor a new D; G'(z) needs G' (already stepped) but not the D update in flight.
+    def _d_real_pre(self, cx):
+        """D.dx on the real batch: independent of the E+G update whose gradients may still be in the all-reduce."""
+        fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
+        x0d, n_log = self._planes(images, idx, cont, fam.d_tables)
+        cx["x0d"], cx["n_log"] = x0d, n_log
+        cx["dx_pre"] = chain_forward(self.pDx, x0d, True, n_log, True)
+
+    def _d_real_rest(self, cx):
         """D gradients on (x, E'(x)) (reference mnist.py:232-235); E' forward only."""
         fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
-        x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
+        x0d, n_log = cx["x0d"], cx["n_log"]
+        x0e, _ = self._planes(images, idx, cont, fam.e_tables)
         ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
-        x0d, _ = self._planes(images, idx, cont, fam.d_tables)
-        d_valid, sD = self._d_forward(x0d, n_log, ex, True)
+        d_valid, sD = self._d_forward(x0d, n_log, ex, True, dx_pre=cx.pop("dx_pre"))
         l, gl = ops.bce_logits(d_valid, 1.0, 1.0)
         cx["out"]["loss_d_real"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0d, idx, fam.d_tables, self.opt_d.grad_views)
-        cx["ex"], cx["n_log"] = ex, n_log
+        cx["ex"] = ex
 
-    def _d_fake_grads(self, cx):
+    def _d_fake_pre(self, cx):
+        """G'(z): independent of the D update whose gradients may still be in the all-reduce."""
+        gin, g_log = self._g_input(cx["zin"], cx["onehots"], cx["cont"])
+        cx["gz"], _ = chain_forward(self.pG, gin, True, g_log, False)
+
+    def _d_fake_rest(self, cx):
         """D gradients on (G'(z), z) (reference mnist.py:237-240); G' forward only."""
         fam, idx, cont, zin = self.family, cx["idx"], cx["cont"], cx["zin"]
-        gin, g_log = self._g_input(zin, cx["onehots"], cont)
-        gz, _ = chain_forward(self.pG, gin, True, g_log, False)
-        x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
+        x0f, _ = self._planes(cx["gz"], idx, cont, fam.d_tables)
         d_fake, sD = self._d_forward(x0f, cx["n_log"], zin, True)
         l, gl = ops.bce_logits(d_fake, 0.0, 1.0)
         cx["out"]["loss_d_fake"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0f, idx, fam.d_tables, self.opt_d.grad_views)
-        cx["gz"] = gz
 
     def _phase_scores(self, cx, average_bn=True):
         """sigma(D(G(z),z)).mean(), sigma(D(x,E(x))).mean() (reference mnist.py:243-248): forward only, train mode,
@@ -332,25 +346,34 @@ class AliStepper:
             dp.average_buffers_(self.bn_buffers, self.pg)
 
     def _segments(self, do_eg):
-        """The iteration cut at its data-parallel exchanges: every segment is pure device work (capturable in a HIP
-        graph); between segments one RCCL all-reduce of a flat gradient buffer runs eagerly on the same stream."""
+        """The iteration as a list of (work, reduce, wait) steps.  ``work(cx)`` is pure device work (capturable in a HIP
+        graph); ``reduce`` names the parameter group whose flat gradient buffer is all-reduced -- asynchronously, on
+        the collective's own stream -- right after the step; a step with ``wait`` first makes the compute stream wait
+        for the all-reduce in flight.  The steps without ``wait`` that follow a reduce overlap with it."""
         segs = []
         if do_eg:
-            segs.append((lambda cx: self._eg_grads(cx), self.opt_eg))
-            segs.append((lambda cx: (self._apply_eg(), self._d_real_grads(cx)), self.opt_d))
+            segs.append((lambda cx: self._eg_grads(cx), self.opt_eg, False))
+            segs.append((lambda cx: self._d_real_pre(cx), None, False))
+            segs.append((lambda cx: (self._apply_eg(), self._d_real_rest(cx)), self.opt_d, True))
         else:
-            segs.append((lambda cx: self._d_real_grads(cx), self.opt_d))
-        segs.append((lambda cx: (self._apply_d(), self._d_fake_grads(cx)), self.opt_d))
-        segs.append((lambda cx: (self._apply_d(), self._phase_scores(cx, average_bn=False)), None))
+            segs.append((lambda cx: (self._d_real_pre(cx), self._d_real_rest(cx)), self.opt_d, False))
+        segs.append((lambda cx: self._d_fake_pre(cx), None, False))
+        segs.append((lambda cx: (self._apply_d(), self._d_fake_rest(cx)), self.opt_d, True))
+        segs.append((lambda cx: (self._apply_d(), self._phase_scores(cx, average_bn=False)), None, True))
         return segs
 
     def _iteration(self, images, c, z, do_eg=True):
         cx = self._begin(images, c, z)
-        if do_eg:
-            self._phase_eg(cx)
-        self._phase_d_real(cx)
-        self._phase_d_fake(cx)
-        self._phase_scores(cx)
+        pending = None
+        for work, group, wait in self._segments(do_eg):
+            if wait and pending is not None:
+                pending.wait()
+                pending = None
+            work(cx)
+            if group is not None and self.world > 1:
+                pending = dp.allreduce_sum_async_(group.grad, self.pg)
+        if self.world > 1:
+            dp.average_buffers_(self.bn_buffers, self.pg)
         return cx["out"]
 
     def _state_tensors(self):
@@ -451,13 +474,13 @@ class AliStepper:
             self._restore(snap)
             pool = torch.cuda.graph_pool_handle()
             graphs, cx = [], None
-            for i, (fn, group) in enumerate(self._segments(do_eg)):
+            for i, (fn, group, wait) in enumerate(self._segments(do_eg)):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     if i == 0:
                         cx = self._begin(st["images"], st["c"], st["z"])
                     fn(cx)
-                graphs.append((g, group))
+                graphs.append((g, group, wait))
                 if group is not None and self.world > 1:   # keep the ranks' collective sequences aligned while capturing
                     dp.allreduce_sum_(group.grad, self.pg)
             if self.world > 1:
@@ -469,10 +492,14 @@ class AliStepper:
         st["z"].copy_(z)
         for k, v in c.items():
             st["c"][k].copy_(v)
-        for g, group in graphs:
+        pending = None
+        for g, group, wait in graphs:
+            if wait and pending is not None:
+                pending.wait()                  # stream-level: the next graph waits for the all-reduce in flight
+                pending = None
             g.replay()
             if group is not None and self.world > 1:
-                dp.allreduce_sum_(group.grad, self.pg)
+                pending = dp.allreduce_sum_async_(group.grad, self.pg)
         if self.world > 1:
             dp.average_buffers_(self.bn_buffers, self.pg)
         return res
