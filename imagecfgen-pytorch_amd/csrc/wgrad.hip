@@ -544,7 +544,7 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (blocks < target && nkt >= 4) {
     S = (int)((target + blocks - 1) / blocks);
     if (S > nkt / 2) S = nkt / 2;
-    if (S > 128) S = 128;
+    { int cap = 512; const char* e = getenv("ALI_WGRAD_SCAP"); if (e && atoi(e) > 0) cap = atoi(e); if (S > cap) S = cap; }
     while (S > 1 && (size_t)S * ((size_t)d.Mtot + 1) * g->K * sizeof(float) > ws_bytes) --S;
     if (S < 1) S = 1;
   }
