@@ -183,6 +183,15 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   __syncthreads();
   const unsigned tapmask = s_tapmask;
 
+  // the epilogue's bias values, requested now: by the end of the k-loop they have long arrived (a dependent load in
+  // the epilogue costs a full memory latency, which is a tenth of a small launch)
+  float bias_pre[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 32 + (lane & 31);
+    bias_pre[j] = (d.ep.bias && n < d.Cout) ? d.ep.bias[n] : 0.f;
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
           const int n = n0 + wn * WN + j * 32 + (lane & 31);
           const bool nok = n < d.Cout;
           const int nc = nok ? n : 0;
-          const float bias = (!partial && ep.bias) ? ep.bias[nc] : 0.f;
+          const float bias = partial ? 0.f : bias_pre[j];
           float mk[8], dy[8];
           if (HAS_MASK) {
 #pragma unroll

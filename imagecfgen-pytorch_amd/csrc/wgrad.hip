@@ -29,6 +29,7 @@ struct WDesc {
   long long s_dc, s_gc, s_tap;
   int Mtot;            // R*S*Cg
   int npix, pix_per_split, splitk;
+  long long slab;      // floats between consecutive slabs: Mtot*Cd plus a pad that breaks the power-of-two stride
   float* db;          // optional: db[dc] = sum_pix dy[pix][dc] (bias gradient), fused into the m-tile-0 blocks
   float* dbws;        // [splitk][Cd] slabs when splitk > 1
 };
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WDesc d) {
         const float v = acc[i][j][r];
         if (partial) {
           const int m = m0 + row;
-          if (m < d.Mtot) d.ws[((long long)blockIdx.z * d.Mtot + m) * d.Cd + n] = v;
+          if (m < d.Mtot) d.ws[(long long)blockIdx.z * d.slab + (long long)m * d.Cd + n] = v;
         } else {
           const long long off = s_rowdst[row];
           if (off >= 0) d.dst[off + n * d.s_dc] = v;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
         const float v = acc[i][j][r];
         if (partial) {
           const int m = m0 + row;
-          if (m < d.Mtot) d.ws[((long long)blockIdx.z * d.Mtot + m) * d.Cd + n] = v;
+          if (m < d.Mtot) d.ws[(long long)blockIdx.z * d.slab + (long long)m * d.Cd + n] = v;
         } else {
           const long long off = s_rowdst[row];
           if (off >= 0) d.dst[off + n * d.s_dc] = v;
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 // dst[dc*s_dc + gc*s_gc + tap*s_tap] = sum_s ws[s][tap*Cg+gc][dc]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log,
                                     int Cd_log, long long s_dc, long long s_gc, long long s_tap,
-                                    float* __restrict__ dst, const float* __restrict__ dbws, float* __restrict__ db) {
+                                    float* __restrict__ dst, const float* __restrict__ dbws, float* __restrict__ db,
+                                    long long slab) {
   const long long total = (long long)Mtot * Cd;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
@@ -418,7 +420,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mto
     const int tap = m / Cg, gc = m - tap * Cg;
     if (dc >= Cd_log || gc >= Cg_log) continue;
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += ws[(long long)s * total + i];
+    for (int s = 0; s < S; ++s) v += ws[(long long)s * slab + i];
     dst[dc * s_dc + gc * s_gc + tap * s_tap] = v;
   }
 }
@@ -427,15 +429,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mto
 // channels] tile.  Slab rows are read as TD-float runs (float4 per lane), the S slabs are split over SGN thread groups
 // (fixed order inside a group, groups combined in order: deterministic), and the tile is written back through LDS so
 // that each dense channel stores one contiguous run of G*T floats of the reference weight layout.
+// slabs of a power-of-two size would all start in the same HBM channel / L2 set: 96 floats (384 B) between them
+constexpr int kSlabPad = 96;
 constexpr int kRedRows = 64, kRedGroups = 16, kRedLds = 256;   // rows per tile, slab groups, groups*rows bound
 template <int TD>
 __global__ void __launch_bounds__(256)
 wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log, int Cd_log,
                          long long s_dc, long long s_gc, long long s_tap, float* __restrict__ dst,
-                         const float* __restrict__ dbws, float* __restrict__ db, int G, int T, int SGN) {
+                         const float* __restrict__ dbws, float* __restrict__ db, int G, int T, int SGN, long long slab) {
   __shared__ float part[kRedLds * (TD + 1)];   // [SGN][RT][TD+1], SGN*RT <= kRedLds
   const int tid = threadIdx.x;
-  const long long total = (long long)Mtot * Cd;
   if (db) {
     const int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
     if (i < Cd_log) {
@@ -460,22 +463,22 @@ wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, 
       for (; sidx + 7 * SGN < S; sidx += 8 * SGN) {      // eight independent loads in flight, summed in slab order
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)(sidx + u * SGN) * total);
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)(sidx + u * SGN) * slab);
 #pragma unroll
         for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
       }
       for (; sidx + 3 * SGN < S; sidx += 4 * SGN) {
-        const float4 v0 = *reinterpret_cast<const float4*>(src + (long long)sidx * total);
-        const float4 v1 = *reinterpret_cast<const float4*>(src + (long long)(sidx + SGN) * total);
-        const float4 v2 = *reinterpret_cast<const float4*>(src + (long long)(sidx + 2 * SGN) * total);
-        const float4 v3 = *reinterpret_cast<const float4*>(src + (long long)(sidx + 3 * SGN) * total);
+        const float4 v0 = *reinterpret_cast<const float4*>(src + (long long)sidx * slab);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + (long long)(sidx + SGN) * slab);
+        const float4 v2 = *reinterpret_cast<const float4*>(src + (long long)(sidx + 2 * SGN) * slab);
+        const float4 v3 = *reinterpret_cast<const float4*>(src + (long long)(sidx + 3 * SGN) * slab);
         acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x;
         acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
         acc.z = (((acc.z + v0.z) + v1.z) + v2.z) + v3.z;
         acc.w = (((acc.w + v0.w) + v1.w) + v2.w) + v3.w;
       }
       for (; sidx < S; sidx += SGN) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (long long)sidx * total);
+        const float4 v = *reinterpret_cast<const float4*>(src + (long long)sidx * slab);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     }
@@ -544,15 +547,23 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (blocks < target && nkt >= 4) {
     S = (int)((target + blocks - 1) / blocks);
     if (S > nkt / 2) S = nkt / 2;
-    { int cap = 512; const char* e = getenv("ALI_WGRAD_SCAP"); if (e && atoi(e) > 0) cap = atoi(e); if (S > cap) S = cap; }
-    while (S > 1 && (size_t)S * ((size_t)d.Mtot + 1) * g->K * sizeof(float) > ws_bytes) --S;
+    {
+      // the slab fold reads S * Mtot * K floats: keep S modest unless the pixel range is so long that two weight
+      // tiles could not fill the chip otherwise (first layers of the spectrogram models)
+      int cap = d.npix >= (1 << 20) ? 512 : 128;
+      const char* e = getenv("ALI_WGRAD_SCAP");
+      if (e && atoi(e) > 0) cap = atoi(e);
+      if (S > cap) S = cap;
+    }
+    while (S > 1 && (size_t)S * (((size_t)d.Mtot + 1) * g->K + kSlabPad) * sizeof(float) > ws_bytes) --S;
     if (S < 1) S = 1;
   }
   d.splitk = S;
   int per = (nkt + S - 1) / S;
   d.pix_per_split = per * wbk;
   d.db = fast ? db : nullptr;
-  d.dbws = d.ws + (size_t)S * d.Mtot * g->K;
+  d.slab = (long long)d.Mtot * g->K + kSlabPad;
+  d.dbws = d.ws + (size_t)S * d.slab;
   dim3 grid(tiles_m, tiles_n, S), block(256);
   if (fast) {
     const unsigned xb = (unsigned)(x_elems * 4), yb = (unsigned)(dy_elems * 4);
@@ -592,7 +603,7 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
       dim3 rgrid((g->C + G - 1) / G, (g->K + TD - 1) / TD);
 #define RLAUNCH(TD_)                                                                                              \
   hipLaunchKernelGGL(wgrad_reduce_tile_kernel<TD_>, rgrid, dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log, \
-                     Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN)
+                     Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN, d.slab)
       if (TD == 32) RLAUNCH(32);
       else if (TD == 16) RLAUNCH(16);
       else if (TD == 8) RLAUNCH(8);
@@ -602,7 +613,7 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
       int nb = (int)((total + 255) / 256);
       if (nb > 4096) nb = 4096;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, d.ws, S, d.Mtot, d.Cg, d.Cd, Cg_log,
-                         Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db);
+                         Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, d.slab);
     }
     rc = check_launch("wgrad_reduce_kernel");
   }
