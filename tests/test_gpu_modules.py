@@ -572,3 +572,27 @@ def test_pickled_module_checkpoint_roundtrip(tmp_path):
     E3 = pm.Encoder()
     E3.load_state_dict(ck["E_state_dict"])
     assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(E3.state_dict().values(), E.state_dict().values()))
+
+
+def test_generator_sampler_equals_the_scoring_loop():
+    """SURVEY 8f.1, scoring path: mean over mc_rounds of G(z_r, a) as one batched, graph-replayed forward == the
+    reference loop (audiomnist_generator_score.py:83-88) to fp32 rounding; weights updated in place are picked up."""
+    from ali_hip.step import GeneratorSampler
+    _, (E, G, D), images, c, z = paired_models("mnist")
+    G.eval()
+    cd = to_dev(c)
+    R, B = 3, images.shape[0]
+    gz = torch.Generator().manual_seed(17)
+    sampler = GeneratorSampler(G)
+    for trial in range(2):
+        zs = torch.randn(R, B, 512, 1, 1, generator=gz).cuda()
+        with torch.no_grad():
+            gen = 0
+            for r in range(R):
+                gen = gen + G(zs[r], cd)
+            gen = gen / R
+        out = sampler(zs, cd)
+        close(out, gen, rtol=1e-5, what=f"sampler trial {trial}")
+        with torch.no_grad():
+            for p in G.parameters():
+                p.mul_(1.01)
