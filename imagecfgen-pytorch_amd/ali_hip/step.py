@@ -424,6 +424,43 @@ class AliStepper:
         for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
             pl.cache.refresh()
 
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        """Resumable checkpoint: the reference's state-dict format (``{E,G,D}_state_dict``, what ``mnist.load_model``
+        / the audio scripts read, mnist.py:302-313) plus what the reference never saves: both Adam states and the
+        iteration counter that keys the dropout masks.  Tensors are cloned to the CPU."""
+        def opt(g):
+            # the device-side count is the authoritative one: graph replays do not run the host-side increment
+            return {"step": int(g.step_t.item()), "exp_avg": g.m.cpu().clone(), "exp_avg_sq": g.v.cpu().clone()}
+        sd = {f"{n}_state_dict": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+              for n, m in (("E", self.E), ("G", self.G), ("D", self.D))}
+        sd.update(optimizer_E=opt(self.opt_eg), optimizer_D=opt(self.opt_d), iteration=int(self.iter_t.item()),
+                  dropout_seed=_dropout._state["seed"])
+        return sd
+
+    def load_state_dict(self, sd):
+        """Inverse of ``state_dict`` (also accepts a checkpoint that only holds the three module state dicts):
+        everything is copied in place, so captured HIP graphs stay valid."""
+        with torch.no_grad():
+            for n, m in (("E", self.E), ("G", self.G), ("D", self.D)):
+                src = sd[f"{n}_state_dict"]
+                for k, v in m.state_dict().items():
+                    v.copy_(src[k])
+            for g, key in ((self.opt_eg, "optimizer_E"), (self.opt_d, "optimizer_D")):
+                o = sd.get(key)
+                if o is None:
+                    g.m.zero_(), g.v.zero_()
+                    g.steps = 0
+                else:
+                    g.m.copy_(o["exp_avg"]), g.v.copy_(o["exp_avg_sq"])
+                    g.steps = int(o["step"])
+                g.step_t.fill_(g.steps)
+            self.iter_t.fill_(int(sd.get("iteration", 0)))
+            if "dropout_seed" in sd:
+                _dropout._state["seed"] = int(sd["dropout_seed"])
+            for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
+                pl.cache.refresh()
+
     def _refresh_d(self):
         with ops.batched_packs():
             self.pDx.cache.refresh()

@@ -596,3 +596,35 @@ def test_generator_sampler_equals_the_scoring_loop():
         with torch.no_grad():
             for p in G.parameters():
                 p.mul_(1.01)
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_stepper_checkpoint_resume_is_exact(capture, tmp_path):
+    """save after 2 iterations, resume in a fresh stepper, 2 more == 4 uninterrupted iterations bit for
+    bit (weights, BN buffers, both Adam states, dropout stream); the file is the reference's state-dict format."""
+    import ali_hip
+    from ali_hip.step import AliStepper
+
+    def fresh():
+        ali_hip.manual_seed(77)
+        _, (E, G, D), st, batches = _stepper_setup(capture=capture)
+        return (E, G, D), st, batches
+
+    def digest(st):
+        return orc.tensor_digest(torch.cat([t.reshape(-1).float().cpu() for t in st._state_tensors()]))
+
+    (_, _, _), ref, batches = fresh()
+    seq = [batches[i % len(batches)] for i in range(4)]
+    for images, c, z in seq:
+        ref.step(images.cuda(), to_dev(c), z.cuda())
+    (E1, G1, D1), first, _ = fresh()
+    for images, c, z in seq[:2]:
+        first.step(images.cuda(), to_dev(c), z.cuda())
+    torch.save(first.state_dict(), tmp_path / "ckpt.tar")
+    ck = torch.load(tmp_path / "ckpt.tar")
+    assert set(ck["D_state_dict"]) == set(D1.state_dict()) and ck["optimizer_D"]["step"] == 4
+    (_, _, _), second, _ = fresh()
+    second.load_state_dict(ck)
+    for images, c, z in seq[2:]:
+        second.step(images.cuda(), to_dev(c), z.cuda())
+    assert digest(second) == digest(ref)
