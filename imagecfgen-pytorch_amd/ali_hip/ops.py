@@ -336,6 +336,13 @@ def col2im(contrib, ldc, bias, out, B, H, W, Hout, Wout, NC, ostride, R, S, stri
     return out
 
 
+def spect_post(y, B, T, F, out, mean=None, std=None, clip_k=3.0):
+    lib = _lib.load()
+    _lib.check(lib.ali_spect_post(_chk(y, "y"), B, T, F, _opt(mean, "mean"), _opt(std, "std"), float(clip_k),
+                                  _chk(out, "out"), _stream()), "ali_spect_post")
+    return out
+
+
 def bce_logits(logit, target, gscale=1.0, want_grad=True):
     """returns (out2 = [loss, mean sigmoid] device tensor, glogit or None)."""
     lib = _lib.load()

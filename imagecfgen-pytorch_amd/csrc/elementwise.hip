@@ -519,6 +519,34 @@ col2im_kernel(const float* __restrict__ contrib, int ldc, const float* __restric
   }
 }
 
+// ---- spectrogram tail: power, log, optional standardise + clip, [B,T,2F] -> [B,F,T] through a 32x32 LDS tile
+__global__ void __launch_bounds__(256)
+spect_post_kernel(const float* __restrict__ y, int T, int F, const float* __restrict__ mean,
+                  const float* __restrict__ stdv, float clip_k, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {                        // rows = frames, columns = frequencies (contiguous in y)
+    const int t = t0 + r, f = f0 + tx;
+    float v = 0.f;
+    if (t < T && f < F) {
+      const float* row = y + ((long long)b * T + t) * (2 * F);
+      const float re = row[f], im = row[F + f];
+      v = logf(re * re + im * im + 1e-6f);
+      if (mean) {
+        v = (v - mean[t]) / (stdv[t] + 1e-6f);
+        v = fminf(fmaxf(v, -clip_k), clip_k) / clip_k;
+      }
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {                        // rows = frequencies, columns = frames (contiguous in out)
+    const int f = f0 + r, t = t0 + tx;
+    if (f < F && t < T) out[((long long)b * F + f) * T + t] = tile[tx][r];
+  }
+}
+
 // ---- BCE with logits against a constant target (single block; B <= a few thousand)
 __global__ void bce_logits_kernel(const float* __restrict__ logit, int B, float target, float gscale,
                                   float* __restrict__ out2, float* __restrict__ glogit) {
@@ -818,6 +846,17 @@ extern "C" int ali_col2im(const float* contrib, int32_t ldc, const float* bias, 
   }
 #undef C2I
   return check_launch("col2im_kernel");
+}
+
+extern "C" int ali_spect_post(const float* y, int32_t B, int32_t T, int32_t F, const float* mean, const float* stdv,
+                              float clip_k, float* out, ali_stream_t stream) {
+  if (!y || !out || B <= 0 || T <= 0 || F <= 0 || B > 65535 || (mean && (!stdv || !(clip_k > 0.f)))) {
+    set_error("ali_spect_post: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(spect_post_kernel, dim3((T + 31) / 32, (F + 31) / 32, B), dim3(256), 0, ST(stream), y, T, F, mean, stdv,
+                     clip_k, out);
+  return check_launch("spect_post_kernel");
 }
 
 extern "C" int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, float* out2, float* glogit,

@@ -197,6 +197,14 @@ int ali_col2im(const float* contrib, int32_t ldc, const float* bias, float* out,
                int32_t Hout, int32_t Wout, int32_t NC, int32_t ostride, int32_t R, int32_t S, int32_t stride,
                int32_t pad, int32_t act, float slope, ali_stream_t stream);
 
+/* Tail of the spectrogram front-end (the step in front of the path): torchaudio.transforms.Spectrogram
+ * (power 2) + (. + 1e-6).log() and, optionally, spect_to_img (audio_mnist.py:116,347-363 and copies).  `y` holds, per
+ * frame (b,t), the windowed DFT as produced by a 1x1 ali_conv_fwd with the [2F x win] cos|sin matrix: re[f] = y[f],
+ * im[f] = y[F+f].  out[b,f,t] = log(re^2 + im^2 + 1e-6); with mean/std (per last-dim index t, as the reference
+ * computes them): clip((. - mean[t]) / (std[t] + 1e-6), -k, k) / k. */
+int ali_spect_post(const float* y, int32_t B, int32_t T, int32_t F, const float* mean, const float* std, float clip_k,
+                   float* out, ali_stream_t stream);
+
 const char* ali_last_error(void);
 int ali_version(void);
 

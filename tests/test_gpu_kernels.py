@@ -252,6 +252,34 @@ def test_col2im_gathers_scatter_form_transposed_conv(Co, stride, pad, opad, R):
     close(nchw(out), ref, rtol=1e-5, what="col2im")
 
 
+@pytest.mark.parametrize("n_fft,win,hop,pad,L", [(255, 128, None, 96, 8000), (511, 128, 24, 64, 2900),
+                                                   (1023, 256, 79, 200, 9000)])
+def test_spectrogram_front_end_vs_torch_stft(n_fft, win, hop, pad, L):
+    """the three dataset adapters' torchaudio.transforms.Spectrogram settings.  torchaudio is absent here:
+    pinned to torch.stft with torchaudio's parameter mapping (pad both sides with zeros, centre=True / reflect, Hann
+    window centred in the n_fft frame, power 2, one-sided)."""
+    _ops()
+    from ali_hip.spectrogram import SpectrogramFrontEnd
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, L, generator=g) * torch.linspace(0.1, 1.0, L)
+    hop_ = hop or win // 2
+    xp = F.pad(x, (pad, pad))
+    spec = torch.stft(xp.double(), n_fft=n_fft, hop_length=hop_, win_length=win,
+                      window=torch.hann_window(win, dtype=torch.float64), center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True).abs().pow(2)
+    ref = (spec + 1e-6).log().float()
+    fe = SpectrogramFrontEnd(n_fft, win, hop, pad)
+    got = fe(x.cuda())
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    # power is compared relative to its scale (the log of a near-zero bin amplifies rounding of the bin itself)
+    close(got.exp(), ref.exp(), rtol=1e-5, what="power spectrogram")
+    mean, std = ref.mean(dim=(0, 1)), ref.std(dim=(0, 1))
+    img = torch.clip((ref - mean) / (std + 1e-6), -3, 3) / 3
+    sel = (ref > ref.max() - 12)                    # bins well above the 1e-6 floor: log is well conditioned there
+    got_img = fe(x.cuda(), mean.cuda(), std.cuda()).cpu()
+    assert (got_img - img)[sel].abs().max().item() < 1e-4
+
+
 def test_assemble_planes_matches_torch_modules():
     ops = _ops()
     g = torch.Generator().manual_seed(2)
