@@ -142,15 +142,33 @@ def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
     return dx
 
 
+_PIXTAB = {}
+
+
+def wgrad_pixtab(g: AliConvGeom, device):
+    """Cached per-geometry pixel table of the weight-gradient kernel (include/ali_hip.h: ali_wgrad_pixtab)."""
+    key = (device.index, g.B, g.H, g.W, g.C, g.P, g.Q, g.stride, g.pad)
+    tab = _PIXTAB.get(key)
+    if tab is None:
+        if len(_PIXTAB) > 256:
+            _PIXTAB.clear()
+        tab = torch.empty(2 * g.B * g.P * g.Q, dtype=torch.int32, device=device)
+        _lib.check(_lib.load().ali_wgrad_pixtab(byref(g), c_void_p(tab.data_ptr()), _stream()), "ali_wgrad_pixtab")
+        _PIXTAB[key] = tab
+    return tab
+
+
 def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap, db=None):
     """``db`` (optional, [cd_log]): also produce the column sums of ``dy`` (Conv2d bias gradient) in the same launch."""
     lib = _lib.load()
     ws = workspace(x.device)
+    tab = wgrad_pixtab(g, x.device) if (g.C % 4 == 0 and g.K % 4 == 0) else None
 
     def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
-                                           s_dc, s_gc, s_tap, _opt(db, "db"), c_void_p(ws.data_ptr()), ws.numel(),
-                                           _stream()), "ali_conv_bwd_weight")
+                                           s_dc, s_gc, s_tap, _opt(db, "db"),
+                                           None if tab is None else c_void_p(tab.data_ptr()), c_void_p(ws.data_ptr()),
+                                           ws.numel(), _stream()), "ali_conv_bwd_weight")
     _launch("wgrad", *_geom_cost(g), go)
     return dst
 

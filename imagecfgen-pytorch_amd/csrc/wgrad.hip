@@ -32,6 +32,7 @@ struct WDesc {
   long long slab;      // floats between consecutive slabs: Mtot*Cd plus a pad that breaks the power-of-two stride
   float* db;          // optional: db[dc] = sum_pix dy[pix][dc] (bias gradient), fused into the m-tile-0 blocks
   float* dbws;        // [splitk][Cd] slabs when splitk > 1
+  const int* pixtab;  // optional [npix][2] (ali_wgrad_pixtab)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VECA, bool VECB>
@@ -207,7 +208,7 @@ __device__ __forceinline__ void w_divmod(int m, int dv, float rcp, int& q, int& 
   else if (r >= dv) { ++q; r -= dv; }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB>
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsigned x_bytes, unsigned dy_bytes) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -258,16 +259,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   f32x4 ra[AP], rb[BP];
   const bool do_db = d.db != nullptr && blockIdx.x == 0;
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-  auto load_a = [&](int pix0, int i) {
+  // TAB: the pixel's (byte offset, packed position) comes from the per-geometry table, fetched one k-tile ahead of the
+  // gather that uses it (entries past pix_end read as 0 = a position outside the map); this thread's tap adds constants
+  using i32x2 = __attribute__((ext_vector_type(2))) int;
+  i32x2 te[AP];
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.pixtab, 0, TAB ? (unsigned)pix_end * 8u : 0u, 0x00020000);
+  const int tapoffA = ((dhA * d.W + dwA) * d.Cg + gcA) * 4;      // (dhA, dwA) carry the -pad; the table does not
+  auto load_te = [&](int pix0, int i) {
     const int pix = pix0 + arow0 + i * AROWS;
+    te[i] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, pix * 8, 0, 0));
+  };
+  auto load_a = [&](int pix0, int i) {
     unsigned off = OOB;
-    if (a_ok && pix < pix_end) {
-      int b, rem, p, q;
-      w_divmod(pix, PQ, rPQ, b, rem);
-      w_divmod(rem, d.Q, rQ, p, q);
-      const int ih = p * d.stride + dhA, iw = q * d.stride + dwA;
-      if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
-        off = (unsigned)(((b * d.H + ih) * d.W + iw) * d.Cg + gcA) * 4u;
+    if (TAB) {
+      // entry: x = byte offset of x[b, p*stride, q*stride, 0]; y = (p*stride + 0x4000) | (q*stride + 0x4000) << 16
+      const int ih = (te[i].y & 0xffff) - 0x4000 + dhA, iw = (int)((unsigned)te[i].y >> 16) - 0x4000 + dwA;
+      if (a_ok && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) off = (unsigned)(te[i].x + tapoffA);
+    } else {
+      const int pix = pix0 + arow0 + i * AROWS;
+      if (a_ok && pix < pix_end) {
+        int b, rem, p, q;
+        w_divmod(pix, PQ, rPQ, b, rem);
+        w_divmod(rem, d.Q, rQ, p, q);
+        const int ih = p * d.stride + dhA, iw = q * d.stride + dwA;
+        if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+          off = (unsigned)(((b * d.H + ih) * d.W + iw) * d.Cg + gcA) * 4u;
+      }
     }
     ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0));
   };
@@ -295,10 +313,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (pix_begin < pix_end) {
+    if (TAB) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) load_te(pix_begin, i);
+    }
 #pragma unroll
     for (int i = 0; i < AP; ++i) load_a(pix_begin, i);
 #pragma unroll
     for (int j = 0; j < BP; ++j) load_b(pix_begin, j);
+    if (TAB) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) load_te(pix_begin + WBK2, i);
+    }
     store_tile(0);
     __syncthreads();
     int buf = 0;
@@ -325,6 +351,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
               if ((x * Q) / NL != s) continue;
               if (x < AP) load_a(nxt, x); else load_b(nxt, x - AP);
             }
+          }
+          if (TAB && s >= Q && s < 2 * Q) {   // second quarter: table entries of the tile after next
+#pragma unroll
+            for (int x = 0; x < AP; ++x)
+              if ((x * Q) / AP == s - Q) load_te(nxt + WBK2, x);
           }
         }
         {  // fragments of k-step ks+1: TM+TN single-float reads, one behind each MFMA of step ks
@@ -399,6 +430,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
       }
     }
   }
+}
+
+__global__ void wgrad_pixtab_kernel(int npix, int P, int Q, int H, int W, int Cg, int stride, int* __restrict__ out) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int b = pix / (P * Q), rem = pix - b * (P * Q);
+  const int p = rem / Q, q = rem - p * Q;
+  out[2 * pix] = ((b * H + p * stride) * W + q * stride) * Cg * 4;
+  out[2 * pix + 1] = (p * stride + 0x4000) | ((q * stride + 0x4000) << 16);
 }
 
 // dst[dc*s_dc + gc*s_gc + tap*s_tap] = sum_s ws[s][tap*Cg+gc][dc]
@@ -501,8 +541,8 @@ wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, 
 using namespace ali;
 
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
-                                   int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db, void* ws,
-                                   size_t ws_bytes, ali_stream_t stream_) {
+                                   int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
+                                   const int32_t* pixtab, void* ws, size_t ws_bytes, ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
     return ALI_ERR_BAD_ARG;
@@ -567,10 +607,18 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   dim3 grid(tiles_m, tiles_n, S), block(256);
   if (fast) {
     const unsigned xb = (unsigned)(x_elems * 4), yb = (unsigned)(dy_elems * 4);
-    if (bm == 64) hipLaunchKernelGGL((wgrad_fast_kernel<64, 64, 2, 2>), grid, block, 0, stream, d, xb, yb);
-    else if (bn == 128) hipLaunchKernelGGL((wgrad_fast_kernel<128, 128, 2, 2>), grid, block, 0, stream, d, xb, yb);
-    else if (bn == 64) hipLaunchKernelGGL((wgrad_fast_kernel<128, 64, 2, 2>), grid, block, 0, stream, d, xb, yb);
-    else hipLaunchKernelGGL((wgrad_fast_kernel<128, 32, 4, 1>), grid, block, 0, stream, d, xb, yb);
+    // the table packs positions as 16-bit fields: maps up to 8191 x 8191
+    d.pixtab = (pixtab && g->H < 0x2000 && g->W < 0x2000 && g->pad < 0x2000) ? pixtab : nullptr;
+#define FLAUNCH(BM_, BN_, WMM, WNN)                                                                               \
+  do {                                                                                                            \
+    if (d.pixtab) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true>), grid, block, 0, stream, d, xb, yb);   \
+    else hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, false>), grid, block, 0, stream, d, xb, yb);   \
+  } while (0)
+    if (bm == 64) FLAUNCH(64, 64, 2, 2);
+    else if (bn == 128) FLAUNCH(128, 128, 2, 2);
+    else if (bn == 64) FLAUNCH(128, 64, 2, 2);
+    else FLAUNCH(128, 32, 4, 1);
+#undef FLAUNCH
   } else {
 #define WLAUNCH(BN_, WMM, WNN)                                                                        \
   do {                                                                                                 \
@@ -620,4 +668,16 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (!rc && db && !fast)   // generic path: bias gradient by the stand-alone column-sum kernels
     rc = ali_colsum(dy, (int64_t)d.npix, Cd_log, g->K, db, ws_all, ws_all_bytes, stream_);
   return rc;
+}
+
+extern "C" int ali_wgrad_pixtab(const AliConvGeom* g, int32_t* out, ali_stream_t stream) {
+  if (!g || !out || g->B <= 0 || g->P <= 0 || g->Q <= 0 || g->stride <= 0 ||
+      (long long)g->B * g->H * g->W * g->C >= (1LL << 29) || (long long)g->B * g->P * g->Q >= (1LL << 28)) {
+    set_error("ali_wgrad_pixtab: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  const int npix = g->B * g->P * g->Q;
+  hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, npix, g->P, g->Q, g->H,
+                     g->W, g->C, g->stride, out);
+  return check_launch("wgrad_pixtab_kernel");
 }

@@ -89,7 +89,14 @@ int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w_cxk,
 int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst,
                         int32_t Cg_log, int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap,
                         float* db /* optional: db[dc] = sum over pixels of dy (Conv2d bias gradient) */,
+                        const int32_t* pixtab /* optional: ali_wgrad_pixtab of the same geometry */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
+/* Per-geometry table for ali_conv_bwd_weight: entry i (2 x int32) of output pixel i = (b,p,q) holds the byte offset of
+ * x[b, p*stride, q*stride, 0] and the packed pair (p*stride, q*stride); the kernel adds its tap's (r-pad, s-pad).  With it the kernel's gather
+ * addresses cost a table read instead of two integer divisions per 16 bytes (fp32 MFMA shares the vector issue
+ * path: that arithmetic is 12-27 % of the kernel's issue slots).  Depends on g only; build once, keep, pass along.
+ * `out` holds 2 * B*P*Q int32. */
+int ali_wgrad_pixtab(const AliConvGeom* g, int32_t* out, ali_stream_t stream);
 
 /* ---- direct kernels for the one-channel ends of the stacks (VALU + LDS, HBM bound) ----------
  * Stride-1 correlations between a K-channel NHWC map `big` [B,P,Q,K] and a 1-channel map `small`
