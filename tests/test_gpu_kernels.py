@@ -280,6 +280,36 @@ def test_spectrogram_front_end_vs_torch_stft(n_fft, win, hop, pad, L):
     assert (got_img - img)[sel].abs().max().item() < 1e-4
 
 
+def test_splitk_last_block_fold_stress():
+    """The in-kernel split-K fold (slabs written and read with device-scope accesses, per-tile arrival counters) under
+    back-to-back launches that reuse the same slabs with different data: a stale slab or a counter left non-zero
+    would show up as an O(1) error.  600 launches, three shapes, alternating inputs."""
+    import os
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    old = os.environ.get("ALI_SPLITK")
+    try:
+        for (B, C, K, S) in ((512, 1024, 1024, 4), (64, 512, 256, 8), (1024, 512, 512, 3)):
+            xs = [torch.randn(B, 1, 1, C, generator=g).cuda() * s for s in (1.0, -2.0)]
+            w = (torch.randn(K, 1, C, generator=g) * 0.05).cuda()
+            geom = ops.geom(B, 1, 1, C, 1, 1, K, 1, 1, 1, 0)
+            os.environ["ALI_SPLITK"] = "1"
+            refs = [ops.conv_fwd(geom, x, w, torch.empty(B, 1, 1, K, device="cuda"), ops.epilogue()).clone() for x in xs]
+            os.environ["ALI_SPLITK"] = str(S)
+            y = torch.empty(B, 1, 1, K, device="cuda")
+            worst = torch.zeros((), device="cuda")
+            for it in range(200):
+                ops.conv_fwd(geom, xs[it & 1], w, y, ops.epilogue())
+                worst = torch.maximum(worst, (y - refs[it & 1]).abs().max())
+            scale = max(r.abs().max().item() for r in refs)
+            assert worst.item() <= 1e-5 * scale, (B, C, K, S, worst.item(), scale)
+    finally:
+        if old is None:
+            os.environ.pop("ALI_SPLITK", None)
+        else:
+            os.environ["ALI_SPLITK"] = old
+
+
 def test_assemble_planes_matches_torch_modules():
     ops = _ops()
     g = torch.Generator().manual_seed(2)
