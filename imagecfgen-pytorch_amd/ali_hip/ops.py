@@ -78,9 +78,10 @@ class KernelProfile:
         torch.cuda.synchronize()
         tab = {}
         for name, flops, ev, desc in self.records:
-            f = tab.setdefault(key(name, desc), {"launches": 0, "flops": 0.0, "ms": 0.0})
+            f = tab.setdefault(key(name, desc), {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             f["launches"] += 1
             f["flops"] += flops
+            f["bytes"] += _geom_bytes(desc)
             f["ms"] += self._ms(ev)
         return tab
 
@@ -100,8 +101,15 @@ def set_profile(p):
 
 
 def _geom_cost(g: AliConvGeom):
+    """(algorithmic FLOP, shape key) of one GEMM launch; algorithmic bytes (both activations + the weights once) are
+    ``_geom_bytes``."""
     return (2.0 * g.B * g.P * g.Q * g.K * g.C * g.R * g.S,
             (g.B, g.H, g.W, g.C, g.P, g.Q, g.K, g.R, g.stride, g.pad))
+
+
+def _geom_bytes(desc):
+    B, H, W, C, P, Q, K, R, stride, pad = desc
+    return 4.0 * (B * H * W * C + B * P * Q * K + K * C * R * R) if B else 0.0
 
 
 def _launch(name, flops, desc, fn):
