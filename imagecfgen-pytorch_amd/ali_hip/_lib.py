@@ -47,10 +47,10 @@ SIGNATURES = {
     "ali_dropout_mask_multi": (c_int32, [c_uint64, c_void_p, POINTER(c_int64), POINTER(c_float), POINTER(c_int32),
                                          POINTER(c_int32), c_int32, c_void_p, c_void_p]),
     "ali_bn_stats": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                               c_void_p]),
+                               c_float, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                               c_void_p, c_size_t, c_void_p]),
     "ali_bn_apply": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-                               c_void_p]),
+                               c_int32, c_int64, c_void_p]),
     "ali_bn_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                              c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ali_bce_logits": (c_int32, [c_void_p, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),

@@ -345,21 +345,15 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
                 if use_batch and bn.num_batches_tracked is not None:
                     _count_batch(bn)
                 t = ops.bn_apply(cur, st4, mask_in, mask_post, B, rows, Cp)
-            else:
-                Bg = B // groups
-                t = torch.empty_like(cur)
-                st4 = []
-                for gi in range(groups):
-                    lo, hi = gi * Bg, (gi + 1) * Bg
-                    mi = None if mask_in is None else mask_in[lo:hi]
-                    mp = None if mask_post is None else mask_post[lo:hi]
-                    sg = ops.bn_stats(cur[lo:hi], mi, Bg, rows, Cp, bn.weight.detach(), bn.bias.detach(),
-                                      bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
-                                      bn.eps, use_batch)
-                    if use_batch and bn.num_batches_tracked is not None:
+            else:       # batched passes: per-pass statistics / running-stat updates, one launch each
+                stg = ops.bn_stats(cur, mask_in, B, rows, Cp, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                   bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch,
+                                   groups=groups)
+                if use_batch and bn.num_batches_tracked is not None:
+                    for _ in range(groups):
                         _count_batch(bn)
-                    ops.bn_apply(cur[lo:hi], sg, mi, mp, Bg, rows, Cp, out=t[lo:hi])
-                    st4.append(sg)
+                t = ops.bn_apply(cur, stg, mask_in, mask_post, B, rows, Cp, groups=groups)
+                st4 = [stg[gi] for gi in range(groups)]
             sv.bn_stats = st4
         elif mask is not None and not mask_applied:
             t = ops.rowmask_mul(cur, mask, B, rows, Cp)

@@ -318,23 +318,26 @@ def dropout_mask_multi(seed, dev_counter, seg_end, seg_p, seg_clog, seg_cpad, ou
     return out
 
 
-def bn_stats(x, mask, B, rows_per_img, C, gamma, beta, running_mean, running_var, momentum, eps, training):
+def bn_stats(x, mask, B, rows_per_img, C, gamma, beta, running_mean, running_var, momentum, eps, training, groups=1):
+    """Returns st [4, C] (mean, invstd, sc, sh), or [groups, 4, C] for ``groups`` batched passes."""
     lib = _lib.load()
     ws = workspace(x.device)
-    st = torch.empty(4, C, dtype=torch.float32, device=x.device)  # mean, invstd, sc, sh
+    st = torch.empty(groups, 4, C, dtype=torch.float32, device=x.device)
     _lib.check(lib.ali_bn_stats(_chk(x, "x"), _opt(mask), B, rows_per_img, C, _opt(gamma), _opt(beta),
                                 _opt(running_mean), _opt(running_var), momentum, eps, int(training),
-                                c_void_p(st[0].data_ptr()), c_void_p(st[1].data_ptr()), c_void_p(st[2].data_ptr()),
-                                c_void_p(st[3].data_ptr()), c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-               "ali_bn_stats")
-    return st
+                                c_void_p(st[0, 0].data_ptr()), c_void_p(st[0, 1].data_ptr()),
+                                c_void_p(st[0, 2].data_ptr()), c_void_p(st[0, 3].data_ptr()), groups, 4 * C,
+                                c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_bn_stats")
+    return st[0] if groups == 1 else st
 
 
-def bn_apply(x, st, mask_in, mask_post, B, rows_per_img, C, out=None):
+def bn_apply(x, st, mask_in, mask_post, B, rows_per_img, C, out=None, groups=1):
     lib = _lib.load()
     out = torch.empty_like(x) if out is None else out
-    _lib.check(lib.ali_bn_apply(_chk(x, "x"), c_void_p(st[2].data_ptr()), c_void_p(st[3].data_ptr()), _opt(mask_in),
-                                _opt(mask_post), _chk(out), B, rows_per_img, C, _stream()), "ali_bn_apply")
+    st0 = st if groups == 1 else st[0]
+    _lib.check(lib.ali_bn_apply(_chk(x, "x"), c_void_p(st0[2].data_ptr()), c_void_p(st0[3].data_ptr()), _opt(mask_in),
+                                _opt(mask_post), _chk(out), B, rows_per_img, C, groups, 4 * C, _stream()),
+               "ali_bn_apply")
     return out
 
 

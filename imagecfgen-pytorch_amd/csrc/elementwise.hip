@@ -194,39 +194,44 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblk, 
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                       float momentum, float eps, int training, float* __restrict__ mean_out,
-                                      float* __restrict__ invstd_out, float* __restrict__ sc, float* __restrict__ sh) {
-  const int c = blockIdx.x;   // one wave per channel
-  float mean, var;
-  if (training) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 64) {
-      s1 += (double)part[((long long)b * 2 + 0) * C + c];
-      s2 += (double)part[((long long)b * 2 + 1) * C + c];
+                                      float* __restrict__ invstd_out, float* __restrict__ sc, float* __restrict__ sh,
+                                      int groups, long long stat_stride) {
+  const int c = blockIdx.x;   // one wave per channel; the groups (batched passes) update the running stats in order
+  for (int gi = 0; gi < groups; ++gi) {
+    const float* pg = part + (long long)gi * nblk * 2 * C;
+    float mean, var;
+    if (training) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int b = threadIdx.x; b < nblk; b += 64) {
+        s1 += (double)pg[((long long)b * 2 + 0) * C + c];
+        s2 += (double)pg[((long long)b * 2 + 1) * C + c];
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      const double m = s1 / (double)count;
+      double v = s2 / (double)count - m * m;
+      if (v < 0.0) v = 0.0;
+      mean = (float)m;
+      var = (float)v;
+      if (running_mean && threadIdx.x == 0) {
+        const double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if (threadIdx.x != 0) return;
-    const double m = s1 / (double)count;
-    double v = s2 / (double)count - m * m;
-    if (v < 0.0) v = 0.0;
-    mean = (float)m;
-    var = (float)v;
-    if (running_mean) {
-      const double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    if (threadIdx.x == 0) {
+      const float invstd = 1.f / sqrtf(var + eps);
+      const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+      const long long o = (long long)gi * stat_stride + c;
+      mean_out[o] = mean;
+      invstd_out[o] = invstd;
+      sc[o] = g * invstd;
+      sh[o] = b - mean * g * invstd;
     }
-  } else {
-    if (threadIdx.x != 0) return;
-    mean = running_mean[c];
-    var = running_var[c];
   }
-  const float invstd = 1.f / sqrtf(var + eps);
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  mean_out[c] = mean;
-  invstd_out[c] = invstd;
-  sc[c] = g * invstd;
-  sh[c] = b - mean * g * invstd;
 }
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                                 const float* __restrict__ mask_in, const float* __restrict__ mask_post,
@@ -337,6 +342,10 @@ rowreduce_vec_kernel(const float* __restrict__ x, const float* __restrict__ g, c
                      const float* __restrict__ invstd, unsigned rows, unsigned rows_per_img, unsigned C, unsigned ld,
                      float* __restrict__ part) {
   __shared__ float4 red1[kEwBlock], red2[kEwBlock];
+  // blockIdx.y = group (independent passes batched along the sample axis: `rows` rows each, own partial block range)
+  x += (size_t)blockIdx.y * rows * ld;
+  if (mask_in) mask_in += (size_t)blockIdx.y * (rows / rows_per_img) * C;
+  part += (size_t)blockIdx.y * gridDim.x * (MODE == 2 ? 1 : 2) * C;
   const unsigned t = threadIdx.x;
   const unsigned C4 = C >> 2, lanes_r = kEwBlock / C4;
   const unsigned tr = t / C4, tc = (t - tr * C4) * 4;
@@ -420,10 +429,17 @@ __device__ __forceinline__ float4 ldc4(const float* p) { return make_float4(p[0]
 __global__ void __launch_bounds__(kEwBlock)
 bn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ sh,
                     const float* __restrict__ mask_in, const float* __restrict__ mask_post, float* __restrict__ out,
-                    unsigned rows, unsigned rows_per_img, unsigned C) {
+                    unsigned rows, unsigned rows_per_img, unsigned C, long long stat_stride) {
   const unsigned C4 = C >> 2, lanes_r = kEwBlock / C4;
   const unsigned tr = threadIdx.x / C4, c = (threadIdx.x - tr * C4) * 4;
   if (tr >= lanes_r) return;
+  // blockIdx.y = group: its own rows, masks and (scale, shift)
+  x += (size_t)blockIdx.y * rows * C;
+  out += (size_t)blockIdx.y * rows * C;
+  if (mask_in) mask_in += (size_t)blockIdx.y * (rows / rows_per_img) * C;
+  if (mask_post) mask_post += (size_t)blockIdx.y * (rows / rows_per_img) * C;
+  sc += blockIdx.y * stat_stride;
+  sh += blockIdx.y * stat_stride;
   const float4 a = ldc4(sc + c), b = ldc4(sh + c);
   const unsigned stride = gridDim.x * lanes_r;
   for (unsigned r = blockIdx.x * lanes_r + tr; r < rows; r += stride) {
@@ -744,42 +760,54 @@ extern "C" int ali_dropout_mask_multi(uint64_t seed, const int64_t* dev_counter,
 extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_t rows_per_img, int32_t C,
                             const float* gamma, const float* beta, float* running_mean, float* running_var,
                             float momentum, float eps, int32_t training, float* mean, float* invstd, float* sc,
-                            float* sh, void* ws, size_t ws_bytes, ali_stream_t stream) {
+                            float* sh, int32_t groups, int64_t stat_stride, void* ws, size_t ws_bytes,
+                            ali_stream_t stream) {
   ws = ws_payload(ws);
   ws_bytes = ws_payload_bytes(ws_bytes);
   if (!x || B <= 0 || rows_per_img <= 0 || C <= 0 || C > kEwBlock || !mean || !invstd || !sc || !sh ||
-      (!training && (!running_mean || !running_var))) {
-    set_error("ali_bn_stats: bad argument (C must be <= 256)");
+      (!training && (!running_mean || !running_var)) || groups < 1 || B % groups != 0 ||
+      (groups > 1 && stat_stride < C)) {
+    set_error("ali_bn_stats: bad argument (C must be <= 256, B a multiple of groups)");
     return ALI_ERR_BAD_ARG;
   }
-  const long long rows = (long long)B * rows_per_img;
-  const bool vec = vec_ok(rows, C) && aligned16(x) && (!mask || aligned16(mask));
+  const int Bg = B / groups;
+  const long long rows = (long long)Bg * rows_per_img;       // per group
+  const bool vec = vec_ok(rows * groups, C) && aligned16(x) && (!mask || aligned16(mask));
   const int nb = vec ? reduce_blocks_vec(rows, C) : reduce_blocks(rows, C);
-  if (!ws || ws_bytes < (size_t)nb * 2 * C * sizeof(float)) { set_error("ali_bn_stats: workspace too small"); return ALI_ERR_WORKSPACE; }
+  if (!ws || ws_bytes < (size_t)groups * nb * 2 * C * sizeof(float)) { set_error("ali_bn_stats: workspace too small"); return ALI_ERR_WORKSPACE; }
   float* part = reinterpret_cast<float*>(ws);
   if (training && vec)
-    hipLaunchKernelGGL(rowreduce_vec_kernel<0>, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, (const float*)nullptr, mask,
+    hipLaunchKernelGGL(rowreduce_vec_kernel<0>, dim3(nb, groups), dim3(kEwBlock), 0, ST(stream), x, (const float*)nullptr, mask,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (unsigned)rows,
                        (unsigned)rows_per_img, (unsigned)C, (unsigned)C, part);
   else if (training)
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, mask, rows, rows_per_img, C, part);
+    for (int gi = 0; gi < groups; ++gi)
+      hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x + (size_t)gi * rows * C,
+                         mask ? mask + (size_t)gi * Bg * C : nullptr, rows, rows_per_img, C, part + (size_t)gi * nb * 2 * C);
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, rows, gamma, beta,
-                     running_mean, running_var, momentum, eps, training, mean, invstd, sc, sh);
+                     running_mean, running_var, momentum, eps, training, mean, invstd, sc, sh, groups,
+                     (long long)stat_stride);
   return check_launch("bn_stats");
 }
 
 extern "C" int ali_bn_apply(const float* x, const float* sc, const float* sh, const float* mask_in,
                             const float* mask_post, float* out, int32_t B, int32_t rows_per_img, int32_t C,
-                            ali_stream_t stream) {
-  if (!x || !sc || !sh || !out || B <= 0 || rows_per_img <= 0 || C <= 0) { set_error("ali_bn_apply: bad argument"); return ALI_ERR_BAD_ARG; }
-  const long long n = (long long)B * rows_per_img * C;
-  if (vec_ok((long long)B * rows_per_img, C) && aligned16(x) && aligned16(out) && (!mask_in || aligned16(mask_in)) &&
+                            int32_t groups, int64_t stat_stride, ali_stream_t stream) {
+  if (!x || !sc || !sh || !out || B <= 0 || rows_per_img <= 0 || C <= 0 || groups < 1 || B % groups != 0) {
+    set_error("ali_bn_apply: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  const int Bg = B / groups;
+  const long long rows = (long long)Bg * rows_per_img, n = rows * C;   // per group
+  if (vec_ok(rows * groups, C) && aligned16(x) && aligned16(out) && (!mask_in || aligned16(mask_in)) &&
       (!mask_post || aligned16(mask_post)))
-    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(ew_grid(n / 4)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in,
-                       mask_post, out, (unsigned)((long long)B * rows_per_img), (unsigned)rows_per_img, (unsigned)C);
+    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(ew_grid(n / 4), groups), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in,
+                       mask_post, out, (unsigned)rows, (unsigned)rows_per_img, (unsigned)C, (long long)stat_stride);
   else
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, sc, sh, mask_in, mask_post, out, n,
-                       rows_per_img, C);
+    for (int gi = 0; gi < groups; ++gi)
+      hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x + (size_t)gi * n,
+                         sc + gi * stat_stride, sh + gi * stat_stride, mask_in ? mask_in + (size_t)gi * Bg * C : nullptr,
+                         mask_post ? mask_post + (size_t)gi * Bg * C : nullptr, out + (size_t)gi * n, n, rows_per_img, C);
   return check_launch("bn_apply_kernel");
 }
 

@@ -162,12 +162,17 @@ int ali_dropout_mask_multi(uint64_t seed, const int64_t* dev_counter, const int6
  * bwd_apply: gx = gamma*invstd*(g~ - dbeta/N - xhat*dgamma/N)   [batch stats]
  *            gx = gamma*invstd*g~                               [eval]
  *            then gx *= mask_in (if given) and *= leaky'(x) (slope >= 0 given). */
+/* groups > 1 (stats, apply): the batch holds that many independent forward passes back to back (B/groups images each);
+ * statistics, running-stat updates (in group order) and scale/shift are per pass; group g's mean/invstd/sc/sh live at
+ * [g*stat_stride + c]. */
 int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_t rows_per_img, int32_t C,
                  const float* gamma, const float* beta, float* running_mean, float* running_var,
                  float momentum, float eps, int32_t training,
-                 float* mean, float* invstd, float* sc, float* sh, void* ws, size_t ws_bytes, ali_stream_t stream);
+                 float* mean, float* invstd, float* sc, float* sh, int32_t groups, int64_t stat_stride,
+                 void* ws, size_t ws_bytes, ali_stream_t stream);
 int ali_bn_apply(const float* x, const float* sc, const float* sh, const float* mask_in, const float* mask_post,
-                 float* out, int32_t B, int32_t rows_per_img, int32_t C, ali_stream_t stream);
+                 float* out, int32_t B, int32_t rows_per_img, int32_t C, int32_t groups, int64_t stat_stride,
+                 ali_stream_t stream);
 int ali_bn_bwd(const float* x, const float* g, const float* mask_in, const float* mask_pre,
                const float* mean, const float* invstd, const float* gamma,
                int32_t B, int32_t rows_per_img, int32_t C, int32_t batch_stats, float lrelu_slope,
