@@ -393,10 +393,12 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0)
                             step, ds, grad_scale, _stream()), "ali_adam")
 
 
-def assemble_planes(X, idx, tables, cont, B, H, W, Cpad):
-    """X [B,H,W] fp32; idx [B,n_emb] int32; tables: list of [n,256] fp32; cont [B,n_cont] or None."""
+def assemble_planes(X, idx, tables, cont, B, H, W, Cpad, out=None):
+    """X [B,H,W] fp32; idx [B,n_emb] int32; tables: list of [n,256] fp32; cont [B,n_cont] or None.
+    ``out``: optional contiguous [B,H,W,Cpad] destination (e.g. one half of a batched-pass buffer)."""
     lib = _lib.load()
-    out = torch.empty(B, H, W, Cpad, dtype=torch.float32, device=X.device)
+    if out is None:
+        out = torch.empty(B, H, W, Cpad, dtype=torch.float32, device=X.device)
     n_emb = len(tables)
     arr = (c_void_p * max(n_emb, 1))(*[t.data_ptr() for t in tables])
     for t in tables:

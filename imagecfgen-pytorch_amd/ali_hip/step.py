@@ -147,13 +147,23 @@ class AliStepper:
                            if any(k == "drop" for k, _ in st.pre))
 
     # ------------------------------------------------------------------ pieces
-    def _planes(self, X, idx, cont, tables):
+    def _planes(self, X, idx, cont, tables, out=None):
         B = X.shape[0]
         H, W = self.family.hw
         n_log = 1 + len(tables) + (0 if cont is None else cont.shape[1])
         out = ops.assemble_planes(X.reshape(B, H, W), idx, [t.detach() for t in tables], cont, B, H, W,
-                                  (n_log + 3) // 4 * 4)
+                                  (n_log + 3) // 4 * 4, out=out)
         return out, n_log
+
+    def _planes_pair(self, Xa, Xb, idx, cont, tables):
+        """The conv inputs of two passes that will run as one 2B batch, assembled straight into its two halves."""
+        B = Xa.shape[0]
+        H, W = self.family.hw
+        n_log = 1 + len(tables) + (0 if cont is None else cont.shape[1])
+        buf = torch.empty(2 * B, H, W, (n_log + 3) // 4 * 4, dtype=torch.float32, device=Xa.device)
+        self._planes(Xa, idx, cont, tables, out=buf[:B])
+        self._planes(Xb, idx, cont, tables, out=buf[B:])
+        return buf, n_log
 
     def _plane_grads(self, g0, x0, idx, tables, dst):
         """Embedding-table gradients from the gradient of the assembled planes (tiny tensors).  ``g0`` is either the
@@ -185,13 +195,14 @@ class AliStepper:
         logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups)
         return logit.reshape(B, 1), (s_dx, s_dz, s_dxz, dx.shape[-1], n_log)
 
-    def _d_forward_pair(self, x0a, zina, x0b, zinb, n_log, save):
+    def _d_forward_pair(self, x0a, zina, x0b, zinb, n_log, save, x0_pair=None):
         """D(a) and D(b) with the same weights as ONE batch of 2B samples (rows [0,B) = a): half the launches, and
         the small 1x1 layers see twice the rows.  BatchNorm statistics, running-stat updates and Dropout2d masks stay
         per pass, in the order a, b (chain_forward groups / dropout.paired_passes)."""
-        B = x0a.shape[0]
+        x0 = x0_pair if x0_pair is not None else torch.cat([x0a, x0b], dim=0)
+        B = x0.shape[0] // 2
         with _dropout.paired_passes(self._n_drop):
-            logit, saved = self._d_forward(torch.cat([x0a, x0b], dim=0), n_log, torch.cat([zina, zinb], dim=0), save, 2)
+            logit, saved = self._d_forward(x0, n_log, torch.cat([zina, zinb], dim=0), save, 2)
         return logit[:B], logit[B:], saved
 
     def _d_backward(self, saved, glogit, need_params, need_x, need_z, planes=None):
@@ -227,13 +238,12 @@ class AliStepper:
                                                    cx["zin"], cx["B"])
         x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
         ex, sE = chain_forward(self.pE, x0e, True, n_log, True)
-        x0d, _ = self._planes(images, idx, cont, fam.d_tables)
         gin, g_log = self._g_input(zin, onehots, cont)
         gz, sG = chain_forward(self.pG, gin, True, g_log, True)
-        x0f, _ = self._planes(gz, idx, cont, fam.d_tables)
         # D(x, E(x)) and D(G(z), z) share the weights: one batch of 2B samples (reference order: real pass first)
-        d_valid, d_fake, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(x0d, ex.reshape(zin.shape), x0f, zin,
-                                                                             n_log, True)
+        x0p, _ = self._planes_pair(images, gz, idx, cont, fam.d_tables)
+        d_valid, d_fake, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(None, ex.reshape(zin.shape), None, zin,
+                                                                             n_log, True, x0_pair=x0p)
         l1, gl1 = ops.bce_logits(d_valid.contiguous(), 0.0, 0.5)
         l2, gl2 = ops.bce_logits(d_fake.contiguous(), 1.0, 0.5)
         cx["out"]["loss_eg"] = (l1[0] + l2[0]) / 2
@@ -334,9 +344,8 @@ class AliStepper:
         """sigma(D(G(z),z)).mean(), sigma(D(x,E(x))).mean() (reference mnist.py:243-248): forward only, train mode,
         re-using G'(z) and E'(x) of the D phases (the reference recomputes identical values)."""
         fam, images, idx, cont, zin = self.family, cx["images"], cx["idx"], cx["cont"], cx["zin"]
-        x0f, _ = self._planes(cx["gz"], idx, cont, fam.d_tables)
-        x0d, _ = self._planes(images, idx, cont, fam.d_tables)
-        dg, de, _ = self._d_forward_pair(x0f, zin, x0d, cx["ex"].reshape(zin.shape), cx["n_log"], False)
+        x0p, _ = self._planes_pair(cx["gz"], images, idx, cont, fam.d_tables)
+        dg, de, _ = self._d_forward_pair(None, zin, None, cx["ex"].reshape(zin.shape), cx["n_log"], False, x0_pair=x0p)
         cx["out"]["dg"] = ops.bce_logits(dg.contiguous(), 0.0, 1.0, want_grad=False)[0][1]
         cx["out"]["de"] = ops.bce_logits(de.contiguous(), 0.0, 1.0, want_grad=False)[0][1]
         _dropout.end_iteration()
