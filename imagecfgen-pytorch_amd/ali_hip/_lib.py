@@ -59,6 +59,8 @@ SIGNATURES = {
     "ali_assemble_planes": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_int32, c_void_p,
                                       c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ali_spect_post": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "ali_plane_table_grad": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32,
+                                       c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ali_col2im": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 12 + [c_float, c_void_p]),
     "ali_tconv1_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_float, c_void_p]),
     "ali_tconv1_dgrad": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p] + [c_int32] * 7

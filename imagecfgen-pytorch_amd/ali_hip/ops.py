@@ -357,6 +357,21 @@ def bn_bwd(x, g, mask_in, mask_pre, st, gamma, B, rows_per_img, C, batch_stats, 
     return out_dgamma, out_dbeta, gx
 
 
+def plane_table_grad(g, g_ch, x0, x_ch, idx, idx_col, n_rows, out=None):
+    """Embedding-table gradient from the gradient ``g`` [B,H,W,Cg] of the assembled planes ``x0`` [B,H,W,Cx]
+    (include/ali_hip.h: ali_plane_table_grad).  Returns / fills ``out`` [n_rows, 256]."""
+    lib = _lib.load()
+    B, H, W, Cg = g.shape
+    if out is None:
+        out = torch.empty(n_rows, 256, dtype=torch.float32, device=g.device)
+    if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()):
+        raise ValueError("idx must be a contiguous int32 CUDA tensor")
+    _lib.check(lib.ali_plane_table_grad(_chk(g, "g"), Cg, g_ch, _chk(x0, "x0"), x0.shape[3], x_ch,
+                                        c_void_p(idx.data_ptr()), idx.shape[1], idx_col, B, H, W, n_rows, _chk(out, "out"),
+                                        _stream()), "ali_plane_table_grad")
+    return out
+
+
 def col2im(contrib, ldc, bias, out, B, H, W, Hout, Wout, NC, ostride, R, S, stride, pad, act=ACT_NONE, slope=0.0):
     """Gather half of a scatter-form transposed convolution (include/ali_hip.h: ali_col2im)."""
     lib = _lib.load()

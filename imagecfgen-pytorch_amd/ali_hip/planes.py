@@ -68,9 +68,7 @@ class PlanesFn(torch.autograd.Function):
             if not ctx.needs_input_grad[4 + j]:
                 gtabs.append(None)
                 continue
-            plane = out[..., 1 + j].reshape(B, H * W)
-            gp = g[..., 1 + j].reshape(B, H * W) * (1 - plane * plane)          # tanh'
-            gtabs.append(plane_to_table_grad(gp, idx[:, j], ctx.table_rows[j], H, W))
+            gtabs.append(ops.plane_table_grad(g.contiguous(), 1 + j, out, 1 + j, idx, j, ctx.table_rows[j]))
         return (gX, None, gcont, None) + tuple(gtabs)
 
 

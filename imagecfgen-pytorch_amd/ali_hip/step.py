@@ -168,13 +168,10 @@ class AliStepper:
     def _plane_grads(self, g0, x0, idx, tables, dst):
         """Embedding-table gradients from the gradient of the assembled planes (tiny tensors).  ``g0`` is either the
         full input gradient [B,H,W,Cpad] or only its embedding planes [B,H,W,len(tables)]."""
-        from .planes import plane_to_table_grad
-        B, H, W, C = g0.shape
-        gofs = 0 if C == len(tables) else 1
+        gofs = 0 if g0.shape[3] == len(tables) else 1
+        g0 = g0.contiguous()
         for j, t in enumerate(tables):
-            plane = x0[..., 1 + j].reshape(B, H * W)
-            gp = g0[..., gofs + j].reshape(B, H * W) * (1 - plane * plane)
-            dst[id(t)].copy_(plane_to_table_grad(gp, idx[:, j], t.shape[0], H, W))
+            ops.plane_table_grad(g0, gofs + j, x0, 1 + j, idx, j, t.shape[0], out=dst[id(t)])
 
     def _g_input(self, z, onehots, cont):
         B = z.shape[0]
@@ -624,11 +621,8 @@ class FinetuneStepper:
         g_x0, _ = chain_backward(self.pE, sE, g_codes.reshape(codes.shape), n_log, bool(emb), True, dst,
                                  gx_planes=emb or None)
         gofs = 0 if (g_x0 is not None and g_x0.shape[-1] == len(emb)) else 1
-        from .planes import plane_to_table_grad
         for j, t in enumerate(fam.e_tables):
-            plane = x0[..., 1 + j].reshape(B, H * W)
-            gp = g_x0[..., gofs + j].reshape(B, H * W) * (1 - plane * plane)
-            dst[id(t)].copy_(plane_to_table_grad(gp, idx[:, j], t.shape[0], H, W))
+            ops.plane_table_grad(g_x0.contiguous(), gofs + j, x0, 1 + j, idx, j, t.shape[0], out=dst[id(t)])
         self.opt_e.adam()
         self.pE.cache.refresh()
         return {"rec": rec, "latent": latent}

@@ -502,6 +502,53 @@ static int reduce_blocks_vec(long long rows, int C) {
   return (int)nb;
 }
 
+// ---- embedding-table gradient of the conditioning planes: one block per table cell, threads over samples.
+// Every thread first gathers the contribution of its (<= 8) samples -- all loads up front --, then the per-class sums
+// are wave reductions in a fixed order: one barrier in total.
+constexpr int kPtgMaxChunks = 8;   // B <= 2048
+__global__ void __launch_bounds__(256)
+plane_table_grad_kernel(const float* __restrict__ g, int g_ld, int g_ch, const float* __restrict__ x, int x_ld, int x_ch,
+                        const int* __restrict__ idx, int idx_ld, int idx_col, int B, int H, int W, int n_rows,
+                        float* __restrict__ out) {
+  __shared__ float red[64][4];
+  const int cell = blockIdx.x, ch = cell >> 4, cw = cell & 15, t = threadIdx.x, wave = t >> 6;
+  // pixels h with floor(h*16/H) == ch:  ceil(ch*H/16) <= h < ceil((ch+1)*H/16)
+  const int h0 = (ch * H + 15) / 16, h1 = ((ch + 1) * H + 15) / 16;
+  const int w0 = (cw * W + 15) / 16, w1 = ((cw + 1) * W + 15) / 16;
+  float val[kPtgMaxChunks];
+  int cls[kPtgMaxChunks];
+#pragma unroll
+  for (int c = 0; c < kPtgMaxChunks; ++c) {
+    const int b = c * 256 + t;
+    val[c] = 0.f;
+    cls[c] = -1;
+    if (b < B) {
+      cls[c] = idx[(long long)b * idx_ld + idx_col];
+      float acc = 0.f;
+      for (int h = h0; h < h1; ++h)
+        for (int w = w0; w < w1; ++w) {
+          const long long pix = ((long long)b * H + h) * W + w;
+          const float p = x[pix * x_ld + x_ch];
+          acc += g[pix * g_ld + g_ch] * (1.f - p * p);
+        }
+      val[c] = acc;
+    }
+  }
+  for (int n0 = 0; n0 < n_rows; n0 += 64) {
+    const int nn = min(64, n_rows - n0);
+    for (int n = 0; n < nn; ++n) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < kPtgMaxChunks; ++c) acc += cls[c] == n0 + n ? val[c] : 0.f;
+      acc = wave_sum(acc);
+      if ((t & 63) == 0) red[n][wave] = acc;
+    }
+    __syncthreads();
+    if (t < nn) out[(n0 + t) * 256 + cell] = ((red[t][0] + red[t][1]) + red[t][2]) + red[t][3];
+    __syncthreads();
+  }
+}
+
 // ---- col2im for transposed convolutions in scatter form (see ali_hip.h): one thread per output pixel, NC channels
 template <int NC>
 __global__ void __launch_bounds__(kEwBlock)
@@ -847,6 +894,19 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
                          lrelu_slope, gx);
   }
   return check_launch("bn_bwd");
+}
+
+extern "C" int ali_plane_table_grad(const float* g, int32_t g_ld, int32_t g_ch, const float* x, int32_t x_ld, int32_t x_ch,
+                                    const int32_t* idx, int32_t idx_ld, int32_t idx_col, int32_t B, int32_t H, int32_t W,
+                                    int32_t n_rows, float* out, ali_stream_t stream) {
+  if (!g || !x || !idx || !out || B <= 0 || B > 256 * kPtgMaxChunks || H <= 0 || W <= 0 || n_rows <= 0 || g_ch < 0 ||
+      g_ch >= g_ld || x_ch < 0 || x_ch >= x_ld || idx_col < 0 || idx_col >= idx_ld) {
+    set_error("ali_plane_table_grad: bad argument (B <= 2048)");
+    return ALI_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(plane_table_grad_kernel, dim3(256), dim3(256), 0, ST(stream), g, g_ld, g_ch, x, x_ld, x_ch, idx, idx_ld,
+                     idx_col, B, H, W, n_rows, out);
+  return check_launch("plane_table_grad_kernel");
 }
 
 extern "C" int ali_col2im(const float* contrib, int32_t ldc, const float* bias, float* out, int32_t B, int32_t H,

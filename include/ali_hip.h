@@ -198,6 +198,15 @@ int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* 
                         const float* cont, int32_t n_cont, float* out, int32_t B, int32_t H, int32_t W,
                         int32_t Cpad, ali_stream_t stream);
 
+/* Backward of ali_assemble_planes for one embedding table (mnist.py:17-18,46-55 and copies: Embedding -> 16x16 ->
+ * nearest Upsample -> Tanh):  out[n][cell] = sum over samples b with idx[b*idx_ld + idx_col] == n and over the pixels
+ * (h,w) that the up-sampling maps to cell (floor(h*16/H)*16 + floor(w*16/W)) of
+ *   g[((b*H+h)*W+w)*g_ld + g_ch] * (1 - x[((b*H+h)*W+w)*x_ld + x_ch]^2)        (tanh' from the stored plane).
+ * Fixed summation order (no atomics).  out is [n_rows][256]. */
+int ali_plane_table_grad(const float* g, int32_t g_ld, int32_t g_ch, const float* x, int32_t x_ld, int32_t x_ch,
+                         const int32_t* idx, int32_t idx_ld, int32_t idx_col, int32_t B, int32_t H, int32_t W,
+                         int32_t n_rows, float* out, ali_stream_t stream);
+
 /* Gather half of a strided transposed convolution in scatter form (ConvTranspose2d forward with one or two output
  * channels -- audio_mnist.py:281, whalecalls.py / esrf_acoustic.py Generator tails -- and the few input planes of a
  * first Conv2d's data gradient that are consumed, audio_mnist.py:203-210): a 1x1 GEMM (ali_conv_fwd) first produces,
