@@ -310,6 +310,24 @@ def test_splitk_last_block_fold_stress():
             os.environ["ALI_SPLITK"] = old
 
 
+@pytest.mark.parametrize("B,H,W,n_rows,Cg,Cx", [(37, 28, 28, 10, 8, 8), (5, 128, 128, 3, 2, 4), (600, 28, 28, 10, 1, 8),
+                                                  (3, 256, 256, 70, 4, 8)])
+def test_plane_table_grad_vs_torch(B, H, W, n_rows, Cg, Cx):
+    """ali_plane_table_grad == tanh' * gradient, nearest-upsampling undone, scattered by class (torch formulation in
+    ali_hip.planes.plane_to_table_grad)."""
+    ops = _ops()
+    from ali_hip.planes import plane_to_table_grad
+    g = torch.Generator().manual_seed(21)
+    g0 = torch.randn(B, H, W, Cg, generator=g).cuda()
+    x0 = torch.tanh(torch.randn(B, H, W, Cx, generator=g)).cuda()
+    idx = torch.randint(0, n_rows, (B, 2), generator=g).to(torch.int32).cuda()
+    gch, xch, col = Cg - 1, 1, 1
+    plane = x0[..., xch].reshape(B, H * W)
+    ref = plane_to_table_grad(g0[..., gch].reshape(B, H * W) * (1 - plane * plane), idx[:, col], n_rows, H, W)
+    got = ops.plane_table_grad(g0, gch, x0, xch, idx, col, n_rows)
+    close(got, ref, rtol=2e-5, what="table grad")
+
+
 def test_assemble_planes_matches_torch_modules():
     ops = _ops()
     g = torch.Generator().manual_seed(2)
