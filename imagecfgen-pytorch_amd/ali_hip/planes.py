@@ -4,7 +4,7 @@ Replaces ``Embedding -> Unflatten(1,16,16) -> Upsample(nearest) -> Tanh``, the
 ``continuous_feature_map`` broadcasts and the channel concat of the reference
 (mnist.py:17-18,24-29,46-55; audio_mnist.py:178-183,203-210; esrf_acoustic.py:163-170)
 with one kernel that writes the NHWC, channel-padded conv input directly.
-Backward (tiny tensors: [B,H*W] planes -> [n,256] tables) uses index_add on the device.
+Backward ([B,H,W] plane gradients -> [n,256] tables): ali_plane_table_grad (fixed summation order).
 """
 import torch
 
