@@ -19,10 +19,9 @@ one RCCL all-reduce per group.  Kernel-layout weight copies have fixed addresses
 re-packed right after the Adam launch that changed them, which makes the whole iteration
 capturable in a HIP graph (``capture=True``).
 """
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
-import torch.nn as nn
 
 from . import dp
 from . import dropout as _dropout
