@@ -13,12 +13,13 @@ import torch
 from . import ops
 
 _state = {"seed": 0x5EED, "offset": 0, "inject": None, "pos": 0, "dev_counter": None,
-          "plan": None, "record": None, "req": 0, "pair": 0}
+          "plan": None, "record": None, "req": 0, "pair": 0, "plans": {}, "anon_plans": {}, "tag": None}
 
 
 def manual_seed(seed: int):
     _state["seed"], _state["offset"] = int(seed), 0
     _state["plan"] = _state["record"] = None
+    _state["anon_plans"].clear()
 
 
 @contextlib.contextmanager
@@ -45,21 +46,23 @@ def paired_passes(n_per_pass: int):
         _state["pair"] = prev
 
 
-def begin_iteration(dev_counter, owner=None):
+def begin_iteration(dev_counter, owner=None, tag=None):
     """Stepper hook: masks of this iteration are keyed by the device-side iteration counter (graph replays
     read its current value) and by positions that restart at 0 every iteration.
 
-    The first iteration of a stepper records its (B, C, p) request sequence; from then on all masks of an
-    iteration are produced by ONE launch (``ali_dropout_mask_multi``, bit-identical draws) and handed out as views."""
+    The first iteration of a stepper (per ``tag`` = batch shape / schedule variant) records its (B, C, p) request
+    sequence; from then on all masks of such an iteration are produced by ONE launch (``ali_dropout_mask_multi``,
+    bit-identical draws) and handed out as views.  The plans live on the owner, one per tag, for its whole life: a
+    captured HIP graph keeps writing into its plan's buffer."""
     _state["dev_counter"], _state["offset"], _state["req"] = dev_counter, 0, 0
-    plan = _state["plan"]
-    if plan is not None and plan["owner"] is not owner:
-        plan = _state["plan"] = None
+    _state["plans"] = owner.__dict__.setdefault("_mask_plans", {}) if owner is not None else _state["anon_plans"]
+    _state["tag"] = tag
+    plan = _state["plan"] = _state["plans"].get(tag)
     if _state["inject"] is not None:
-        _state["record"] = None
+        _state["plan"] = _state["record"] = None
         return
     if plan is None:
-        _state["record"] = {"owner": owner, "req": []}
+        _state["record"] = {"req": []}
         return
     _state["record"] = None
     ops.dropout_mask_multi(_state["seed"], dev_counter, plan["ends"], plan["ps"], plan["clog"], plan["cpad"],
@@ -76,9 +79,9 @@ def end_iteration():
         off += B * cpad
         ends.append(off)
     dev = rec["device"]
-    _state["plan"] = {"owner": rec["owner"], "req": rec["req"], "ends": ends, "ps": [r[2] for r in rec["req"]],
-                      "clog": [r[1] for r in rec["req"]], "cpad": [r[3] for r in rec["req"]],
-                      "buf": torch.empty(off, dtype=torch.float32, device=dev)}
+    _state["plans"][_state["tag"]] = {"req": rec["req"], "ends": ends, "ps": [r[2] for r in rec["req"]],
+                                      "clog": [r[1] for r in rec["req"]], "cpad": [r[3] for r in rec["req"]],
+                                      "buf": torch.empty(off, dtype=torch.float32, device=dev)}
 
 
 def masks_consumed() -> int:
@@ -117,7 +120,7 @@ def next_mask(B: int, C: int, p: float, device, cpad=None) -> torch.Tensor:
             _state["req"] = i + 1
             _state["offset"] += B * C
             return plan["buf"][lo:lo + B * cpad].view(B, cpad)
-        _state["plan"] = None          # request sequence changed: fall back to one launch per mask
+        _state["plan"] = None          # request sequence changed: one launch per mask for the rest of this iteration
     m = ops.dropout_mask(_state["seed"], _state["offset"], p, B, C, device, _state["dev_counter"])
     _state["offset"] += B * C
     if rec is not None:

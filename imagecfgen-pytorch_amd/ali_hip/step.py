@@ -137,7 +137,7 @@ class AliStepper:
         self.capture = capture
         self.segmented = False     # tests: force the data-parallel (segmented) replay on a single rank
         self._capture_snapshot = None
-        self._graph = None
+        self._graph = {}           # captured graphs by (input shapes, do_eg): a ragged last batch keeps its own
 
         self.bn_buffers = [b for n_, b in D.named_buffers() if "running" in n_]
         self.iter_t = torch.zeros(1, dtype=torch.int64, device=self.opt_d.flat.device)
@@ -219,10 +219,10 @@ class AliStepper:
         return gx0, gz
 
     # ------------------------------------------------------------------ the iteration, phase by phase
-    def _begin(self, images, c, z):
+    def _begin(self, images, c, z, do_eg=True):
         B = images.shape[0]
         self.iter_t += 1
-        _dropout.begin_iteration(self.iter_t, owner=self)
+        _dropout.begin_iteration(self.iter_t, owner=self, tag=(B, bool(do_eg)))
         _chain.defer_batch_counts()
         idx, cont, onehots = self.family.conditioning(c)
         return {"images": images, "B": B, "idx": idx, "cont": cont, "onehots": onehots,
@@ -368,7 +368,7 @@ class AliStepper:
         return segs
 
     def _iteration(self, images, c, z, do_eg=True):
-        cx = self._begin(images, c, z)
+        cx = self._begin(images, c, z, do_eg)
         pending = None
         for work, group, wait in self._segments(do_eg):
             if wait and pending is not None:
@@ -492,7 +492,7 @@ class AliStepper:
                 return self._replay_segments(images, c, z, do_eg)
             return self._replay(images, c, z, do_eg)
         except Exception as e:  # graph capture refused (driver / RCCL combination): keep training, eagerly
-            if self._graph is not None:
+            if self._graph:
                 raise
             import warnings
             warnings.warn(f"AliStepper: HIP graph capture failed ({e!r}); continuing with eager launches")
@@ -504,7 +504,7 @@ class AliStepper:
     def _replay_segments(self, images, c, z, do_eg):
         """Data-parallel replay: one HIP graph per segment, the gradient all-reduces in between launched eagerly."""
         key = ("seg", tuple(images.shape), do_eg)
-        if self._graph is None or self._graph[0] != key:
+        if key not in self._graph:
             st = {"images": images.clone(), "z": z.clone(), "c": {k: v.clone() for k, v in c.items()}}
             snap = self._snapshot()
             self._capture_snapshot = snap
@@ -520,7 +520,7 @@ class AliStepper:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     if i == 0:
-                        cx = self._begin(st["images"], st["c"], st["z"])
+                        cx = self._begin(st["images"], st["c"], st["z"], do_eg)
                     fn(cx)
                 graphs.append((g, group, wait))
                 if group is not None and self.world > 1:   # keep the ranks' collective sequences aligned while capturing
@@ -528,8 +528,8 @@ class AliStepper:
             if self.world > 1:
                 dp.average_buffers_(self.bn_buffers, self.pg)
             self._restore(snap)                 # capture executes nothing, but the eager collectives above ran
-            self._graph = (key, graphs, st, cx["out"])
-        _, graphs, st, res = self._graph
+            self._graph[key] = (graphs, st, cx["out"])
+        graphs, st, res = self._graph[key]
         st["images"].copy_(images)
         st["z"].copy_(z)
         for k, v in c.items():
@@ -548,7 +548,7 @@ class AliStepper:
 
     def _replay(self, images, c, z, do_eg):
         key = (tuple(images.shape), do_eg)
-        if self._graph is None or self._graph[0] != key:
+        if key not in self._graph:
             st = {"images": images.clone(), "z": z.clone(), "c": {k: v.clone() for k, v in c.items()}}
             snap = self._snapshot()
             self._capture_snapshot = snap
@@ -561,8 +561,8 @@ class AliStepper:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 res = self._iteration(st["images"], st["c"], st["z"], do_eg)
-            self._graph = (key, graph, st, res)
-        _, graph, st, res = self._graph
+            self._graph[key] = (graph, st, res)
+        graph, st, res = self._graph[key]
         st["images"].copy_(images)
         st["z"].copy_(z)
         for k, v in c.items():

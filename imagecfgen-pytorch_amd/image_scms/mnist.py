@@ -161,13 +161,26 @@ def train(x_train: torch.Tensor,
           save_images_every=2,
           image_output_path='',
           batch_size=64,
-          d_updates_per_g_update=1):
-    """Same signature, RNG order and return value as the reference's train (mnist.py:157-299)."""
+          d_updates_per_g_update=1,
+          use_stepper=None):
+    """Same signature, RNG order and return value as the reference's train (mnist.py:157-299).
+
+    On a CUDA device the iteration runs on the hand-scheduled ``AliStepper`` (HIP-graph replay; ``use_stepper=False``
+    keeps the autograd schedule on the same kernels); the two returned optimisers are then its flat Adam groups
+    (``state_dict`` / ``zero_grad`` / ``step`` like ``torch.optim.Adam``).  CPU devices run the stock torch ops."""
     E, G, D = Encoder().to(device), Generator().to(device), Discriminator().to(device)
     for m in (E, G, D):
         m.apply(init_weights)
-    optimizer_E = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=l_rate, betas=(0.5, 0.999))
-    optimizer_D = torch.optim.Adam(D.parameters(), lr=l_rate, betas=(0.5, 0.999))
+    if use_stepper is None:
+        use_stepper = torch.device(device).type == "cuda"
+    stepper = None
+    if use_stepper:
+        from ali_hip.step import AliStepper
+        stepper = AliStepper(E, G, D, lr=l_rate, betas=(0.5, 0.999), capture=True)
+        optimizer_E, optimizer_D = stepper.opt_eg, stepper.opt_d
+    else:
+        optimizer_E = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=l_rate, betas=(0.5, 0.999))
+        optimizer_D = torch.optim.Adam(D.parameters(), lr=l_rate, betas=(0.5, 0.999))
     gan_loss = nn.BCEWithLogitsLoss()
 
     for epoch in range(n_epochs):
@@ -185,8 +198,11 @@ def train(x_train: torch.Tensor,
             images, c = _scale_batch(images, attrs, attr_stats, device)
             z_mean = torch.zeros((len(images), LATENT_DIM, 1, 1)).float()
             z = torch.normal(z_mean, z_mean + 1).to(device)               # sampled on the host like the reference
-            r = ali_step(E, G, D, optimizer_E, optimizer_D, images, c, z,
-                         do_eg=(i % d_updates_per_g_update == 0), gan_loss=gan_loss)
+            if stepper is not None:
+                r = stepper.step(images, c, z, do_eg=(i % d_updates_per_g_update == 0))
+            else:
+                r = ali_step(E, G, D, optimizer_E, optimizer_D, images, c, z,
+                             do_eg=(i % d_updates_per_g_update == 0), gan_loss=gan_loss)
             d_score += r["dg"]                                            # accumulated on device: one sync per epoch
             eg_score += r["de"]
         print(d_score.item() / num_batches, eg_score.item() / num_batches)

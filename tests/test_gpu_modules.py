@@ -628,3 +628,33 @@ def test_stepper_checkpoint_resume_is_exact(capture, tmp_path):
     for images, c, z in seq[2:]:
         second.step(images.cuda(), to_dev(c), z.cuda())
     assert digest(second) == digest(ref)
+
+
+def test_mnist_train_entry_point_on_cuda(tmp_path):
+    """image_scms.mnist.train(device='cuda') -- the reference's own entry point -- on the stepper: ragged last batch
+    (160 = 2*64 + 32: two captured graphs alternate over 2 epochs), d_updates_per_g_update, finite scores, and the
+    returned modules / optimisers usable the way train_mnist_image_scm.py:61-67 uses them (pickled to a .tar)."""
+    import ali_hip
+    import image_scms.mnist as pm
+    ali_hip.manual_seed(4)
+    torch.manual_seed(4)
+    np.random.seed(4)
+    x, a = orc.synth_morphomnist(160, seed=3)
+    E, G, D, oD, oE = pm.train(x, a, n_epochs=2, device="cuda", save_images_every=None, batch_size=64,
+                               d_updates_per_g_update=2)
+    assert all(torch.isfinite(p).all() for m in (E, G, D) for p in m.parameters())
+    assert int(D.dx[4].num_batches_tracked) > 0
+    Eb, Gb, Db = pm.Encoder(), pm.Generator(), pm.Discriminator()
+    torch.manual_seed(4)
+    moved = sum(float((p.detach().cpu() - q.detach()).abs().sum()) for p, q in zip(E.parameters(), Eb.parameters()))
+    assert moved > 0
+    torch.save({"E": E, "G": G, "D": D, "optimizer_D": oD, "optimizer_E": oE}, tmp_path / "model.tar")
+    back = torch.load(tmp_path / "model.tar", weights_only=False)
+    E2, G2 = back["E"].cuda().eval(), back["G"].cuda().eval()
+    images, c = pm._scale_batch(x[:8], {k: v[:8] for k, v in a.items()},
+                                {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"},
+                                "cuda")
+    with torch.no_grad():
+        rec = G2(E2(images, c), c)
+    assert rec.shape == (8, 1, 28, 28) and torch.isfinite(rec).all()
+    assert back["optimizer_D"].state_dict()["step"] > 0
