@@ -114,12 +114,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # one rank per GPU over RCCL.  Rehearsal on a box with fewer GPUs than ranks (ALI_DIST_BACKEND=gloo): the ranks
+    # share the devices round-robin and exchange over gloo -- same schedule, same collective calls, not a measurement.
+    backend = os.environ.get("ALI_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     import ali_hip
@@ -248,7 +255,7 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{names[args.workload]} synthetic, bs={bs}/GPU, fp32 MFMA, mode={args.mode}"
-                                   f"{'' if args.no_graph or world > 1 or args.mode != 'stepper' else '+hipgraph'}",
+                                   f"{'' if args.no_graph or args.mode != 'stepper' else ('+hipgraph' if world == 1 else '+hipgraph-segments')}",
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "roofline": roof,
             "step_roofline": {"hbm_frac": round(per_gpu * ALG_BYTES_PER_IMG / (PEAK_HBM_GBS * 1e9), 4),
