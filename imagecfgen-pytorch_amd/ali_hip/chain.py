@@ -39,31 +39,35 @@ class PackCache:
     """Kernel-layout copies of one parameter (the reference layouts stay the master copies: Conv
     [Cout,Cin,kh,kw], ConvT [Cin,Cout,kh,kw], Linear [out,in]).
 
-    Dynamic mode (autograd modules): a copy is rebuilt when the parameter's version / storage changes.
-    Static mode (AliStepper, graph capture): buffers keep their addresses and are refreshed explicitly
-    by ``refresh()`` right after the optimiser kernel that changed the parameters."""
+    A copy is rebuilt when the parameter's version / storage changed since it was built (``load_state_dict``, a
+    ``torch.optim`` step, any in-place edit bumps the version).  Static mode (AliStepper, graph capture): the rebuild
+    happens IN PLACE so buffers keep their addresses, and ``refresh()`` rewrites every copy right after the optimiser
+    kernel that changed the parameters (that kernel works on raw pointers and does not bump versions)."""
 
     def __init__(self):
         self.store = {}
         self.static = False
 
+    @staticmethod
+    def _tag(param):
+        return (param.data_ptr(), param._version, tuple(param.shape))
+
     def get(self, key, param: torch.Tensor, builder):
         hit = self.store.get(key)
-        if self.static and hit is not None:
-            return hit[1]
-        tag = (param.data_ptr(), param._version, tuple(param.shape))
+        tag = self._tag(param)
         if hit is not None and hit[0] == tag:
             return hit[1]
         with torch.no_grad():
             val = builder(hit[1] if (hit is not None and self.static) else None)
-        self.store[key] = (tag, val, builder)
+        self.store[key] = (tag, val, builder, param)
         return val
 
     def refresh(self):
         with torch.no_grad():
-            for key, (tag, val, builder) in list(self.store.items()):
+            for key, (tag, val, builder, param) in list(self.store.items()):
                 out = builder(val)
                 assert out.data_ptr() == val.data_ptr()
+                self.store[key] = (self._tag(param), val, builder, param)
 
 
 class ChainPlan:

@@ -17,8 +17,9 @@ def world_size(group=None) -> int:
 
 
 def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place sum over ranks of one flat fp32 buffer (one collective per parameter group)."""
-    if world_size(group) > 1:
+    """In-place sum over ranks of one flat fp32 buffer (one collective per parameter group).  Issued whenever a
+    process group exists -- also on a 1-rank group, where it is the identity but still exercises the backend."""
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
@@ -31,9 +32,9 @@ def allreduce_sum_async_(flat: torch.Tensor, group=None):
 
 def average_buffers_(buffers, group=None):
     """Average a list of small tensors (BatchNorm running stats) with a single collective."""
-    w = world_size(group)
-    if w <= 1 or not buffers:
+    if not (dist.is_available() and dist.is_initialized()) or not buffers:
         return
+    w = world_size(group)
     flat = torch.cat([b.reshape(-1).float() for b in buffers])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.mul_(1.0 / w)

@@ -71,6 +71,8 @@ class FlatGroup:
         self.adam()
 
     def state_dict(self):
+        # the device-side count is the authoritative one: HIP-graph replays do not run the host-side increment
+        self.steps = int(self.step_t.item())
         return {"step": self.steps, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas,
                 "eps": self.eps}
 
@@ -134,6 +136,7 @@ class AliStepper:
             pl.cache.static = True
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.dist = process_group is not None      # a 1-rank group still issues every collective (tests the RCCL path)
         self.capture = capture
         self.segmented = False     # tests: force the data-parallel (segmented) replay on a single rank
         self._capture_snapshot = None
@@ -280,21 +283,21 @@ class AliStepper:
 
     def _phase_eg(self, cx):
         self._eg_grads(cx)
-        if self.world > 1:
+        if self.dist:
             dp.allreduce_sum_(self.opt_eg.grad, self.pg)
         self._apply_eg()
 
     def _phase_d_real(self, cx):
         self._d_real_pre(cx)
         self._d_real_rest(cx)
-        if self.world > 1:
+        if self.dist:
             dp.allreduce_sum_(self.opt_d.grad, self.pg)
         self._apply_d()
 
     def _phase_d_fake(self, cx):
         self._d_fake_pre(cx)
         self._d_fake_rest(cx)
-        if self.world > 1:
+        if self.dist:
             dp.allreduce_sum_(self.opt_d.grad, self.pg)
         self._apply_d()
 
@@ -346,7 +349,7 @@ class AliStepper:
         cx["out"]["de"] = ops.bce_logits(de.contiguous(), 0.0, 1.0, want_grad=False)[0][1]
         _dropout.end_iteration()
         _chain.flush_batch_counts()        # all BatchNorm num_batches_tracked increments of the iteration: one launch
-        if self.world > 1 and average_bn:
+        if self.dist and average_bn:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
             dp.average_buffers_(self.bn_buffers, self.pg)
 
@@ -375,9 +378,9 @@ class AliStepper:
                 pending.wait()
                 pending = None
             work(cx)
-            if group is not None and self.world > 1:
+            if group is not None and self.dist:
                 pending = dp.allreduce_sum_async_(group.grad, self.pg)
-        if self.world > 1:
+        if self.dist:
             dp.average_buffers_(self.bn_buffers, self.pg)
         return cx["out"]
 
@@ -461,8 +464,11 @@ class AliStepper:
                     g.steps = int(o["step"])
                 g.step_t.fill_(g.steps)
             self.iter_t.fill_(int(sd.get("iteration", 0)))
-            if "dropout_seed" in sd:
+            if "dropout_seed" in sd and int(sd["dropout_seed"]) != _dropout._state["seed"]:
+                # the seed is a launch argument of the mask kernel: graphs captured with the old one must go
                 _dropout._state["seed"] = int(sd["dropout_seed"])
+                self._graph.clear()
+                self.__dict__.pop("_mask_plans", None)
             for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
                 pl.cache.refresh()
 
@@ -488,12 +494,12 @@ class AliStepper:
         if not self.capture:
             return self._iteration(images, c, z, do_eg)
         try:
-            if self.world > 1 or self.segmented:
+            if self.dist or self.segmented:
                 return self._replay_segments(images, c, z, do_eg)
             return self._replay(images, c, z, do_eg)
-        except Exception as e:  # graph capture refused (driver / RCCL combination): keep training, eagerly
-            if self._graph:
-                raise
+        except RuntimeError as e:  # graph capture refused (driver / RCCL combination): keep training, eagerly
+            if self._graph or not any(w in str(e).lower() for w in ("captur", "graph")):
+                raise              # a failure of a graph that already ran, or an error that is not about capture
             import warnings
             warnings.warn(f"AliStepper: HIP graph capture failed ({e!r}); continuing with eager launches")
             self.capture = False
@@ -523,9 +529,9 @@ class AliStepper:
                         cx = self._begin(st["images"], st["c"], st["z"], do_eg)
                     fn(cx)
                 graphs.append((g, group, wait))
-                if group is not None and self.world > 1:   # keep the ranks' collective sequences aligned while capturing
+                if group is not None and self.dist:   # keep the ranks' collective sequences aligned while capturing
                     dp.allreduce_sum_(group.grad, self.pg)
-            if self.world > 1:
+            if self.dist:
                 dp.average_buffers_(self.bn_buffers, self.pg)
             self._restore(snap)                 # capture executes nothing, but the eager collectives above ran
             self._graph[key] = (graphs, st, cx["out"])
@@ -540,9 +546,9 @@ class AliStepper:
                 pending.wait()                  # stream-level: the next graph waits for the all-reduce in flight
                 pending = None
             g.replay()
-            if group is not None and self.world > 1:
+            if group is not None and self.dist:
                 pending = dp.allreduce_sum_async_(group.grad, self.pg)
-        if self.world > 1:
+        if self.dist:
             dp.average_buffers_(self.bn_buffers, self.pg)
         return res
 

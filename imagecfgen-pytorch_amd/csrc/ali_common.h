@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/ali_hip.h"
 
 namespace ali {
@@ -16,6 +17,24 @@ inline int check_launch(const char* what) {
     return ALI_ERR_LAUNCH;
   }
   return ALI_OK;
+}
+
+// Developer tuning knobs (scratch/ sweeps), read from the environment ONCE per process; 0 = use the built-in rule.
+struct Tuning {
+  int bm, bn, splitk;                       // ALI_BM / ALI_BN / ALI_SPLITK: force the gconv tile / split
+  long long wgrad_small;                    // ALI_WGRAD_SMALL
+  int wgrad_blocks, wgrad_scap;             // ALI_WGRAD_BLOCKS / ALI_WGRAD_SCAP
+};
+inline const Tuning& tuning() {
+  static const Tuning t = [] {
+    auto num = [](const char* name) -> long long { const char* e = getenv(name); return e ? atoll(e) : 0; };
+    Tuning v;
+    v.bm = (int)num("ALI_BM"); v.bn = (int)num("ALI_BN"); v.splitk = (int)num("ALI_SPLITK");
+    v.wgrad_small = getenv("ALI_WGRAD_SMALL") ? num("ALI_WGRAD_SMALL") : -1;
+    v.wgrad_blocks = (int)num("ALI_WGRAD_BLOCKS"); v.wgrad_scap = (int)num("ALI_WGRAD_SCAP");
+    return v;
+  }();
+  return t;
 }
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;

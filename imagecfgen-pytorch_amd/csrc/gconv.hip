@@ -535,6 +535,20 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     // counter sums the slabs in slab order (deterministic whichever block that is) and runs the real epilogue.
     // Slab stores / loads are device-scope (sc1) accesses -- written through to memory, never served from another
     // XCD's stale L2 line -- so no cache-wide release / acquire fence is needed, only "my stores have completed".
+    //
+    // Why the last block sees every slab (hardware-level argument; tests/test_gpu_kernels.py stress-tests it):
+    //  1. a slab element is written by a relaxed agent-scope atomic store = global_store ... sc1: the write goes
+    //     through this XCD's L2 to the device-coherent level and is acknowledged from there;
+    //  2. s_waitcnt(0) retires only when all of this thread's stores are acknowledged, and the barrier behind it
+    //     (a workgroup fence for the compiler: no memory access is moved across it) means "every store of this
+    //     block is complete at device scope" before thread 0 issues the counter atomic;
+    //  3. the counter is an agent-scope RMW executed at that same coherent level; the block that reads S-1 from it
+    //     therefore runs after all S-1 other RMWs, each of which was issued after its block's step 2;
+    //  4. the winner's slab loads are issued after the barrier that publishes s_last (so after the RMW returned) and
+    //     are buffer_load ... sc1: device-scope loads, never served from a line this XCD's L2 kept from an earlier
+    //     launch.  The counter is reset by the winner alone, after all arrivals: the next launch (stream order)
+    //     finds it at zero.
+    // Nothing else is shared between the blocks of a tile, so no cache-wide fence is required.
     run_epilogue(F_{}, F_{}, true, d.ws + (long long)blockIdx.z * d.out_elems);
     __shared__ int s_last;
     __builtin_amdgcn_s_waitcnt(0);
@@ -634,11 +648,7 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   const bool pow2 = vec && (d.Cin == 4 || d.Cin == 8 || d.Cin == 16) && max_taps <= kMaxTaps;
   TileCfg tc = pick_tile(Mtot, d.Cout);
   if (!vec && tc.bn == 128) tc.bn = 64;
-  {
-    const char* bm = getenv("ALI_BM");
-    const char* bn = getenv("ALI_BN");
-    if (bm && bn && atoi(bm) > 0) { tc.bm = atoi(bm); tc.bn = atoi(bn); }
-  }
+  if (tuning().bm > 0 && tuning().bn > 0) { tc.bm = tuning().bm; tc.bn = tuning().bn; }
   int tiles = 0;
   for (int i = 0; i < d.nphase; ++i) {
     // small maps with a large batch: order rows (pixel, image) so that every M-tile sees one pixel position
@@ -680,10 +690,8 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     while (S > 1 && (size_t)S * d.out_elems * sizeof(float) > ws_payload_bytes(ws_bytes)) --S;
     if (S < 1) S = 1;
   }
-  {
-    const char* fs = getenv("ALI_SPLITK");
-    if (fs && atoi(fs) > 0 && (size_t)atoi(fs) * d.out_elems * sizeof(float) <= ws_payload_bytes(ws_bytes)) S = atoi(fs);
-  }
+  if (tuning().splitk > 0 && (size_t)tuning().splitk * d.out_elems * sizeof(float) <= ws_payload_bytes(ws_bytes))
+    S = tuning().splitk;
   if (blocks > (long long)(kWsReserved / sizeof(int)) || !ws) S = 1;   // one arrival counter per tile
   while (S > 1 && (long long)S * d.out_elems * 4 >= 0xFF000000LL) --S;  // slabs addressed with 32-bit byte offsets
   d.splitk = S;

@@ -571,7 +571,7 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     // ... but a long pixel reduction (spectrogram layers) re-reads both operands once per tile pair: larger tiles,
     // the grid depth comes from the split over pixels
     long long small_lim = d.npix >= 200000 ? 16 : 2 * kNumCU;
-    { const char* e = getenv("ALI_WGRAD_SMALL"); if (e) small_lim = atoll(e); }
+    if (tuning().wgrad_small >= 0) small_lim = tuning().wgrad_small;
     if (g->K > 32 && b64 <= small_lim) { bm = 64; bn = 64; }
     else if (g->K > 64) { bm = 128; bn = 128; }
     else if (g->K > 32) { bm = 128; bn = 64; }
@@ -583,7 +583,7 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   int S = 1;
   const int nkt = (d.npix + wbk - 1) / wbk;
   int target = 4 * kNumCU;
-  { const char* e = getenv("ALI_WGRAD_BLOCKS"); if (e && atoi(e) > 0) target = atoi(e); }
+  if (tuning().wgrad_blocks > 0) target = tuning().wgrad_blocks;
   if (blocks < target && nkt >= 4) {
     S = (int)((target + blocks - 1) / blocks);
     if (S > nkt / 2) S = nkt / 2;
@@ -591,8 +591,7 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
       // the slab fold reads S * Mtot * K floats: keep S modest unless the pixel range is so long that two weight
       // tiles could not fill the chip otherwise (first layers of the spectrogram models)
       int cap = d.npix >= (1 << 20) ? 512 : 128;
-      const char* e = getenv("ALI_WGRAD_SCAP");
-      if (e && atoi(e) > 0) cap = atoi(e);
+      if (tuning().wgrad_scap > 0) cap = tuning().wgrad_scap;
       if (S > cap) S = cap;
     }
     while (S > 1 && (size_t)S * (((size_t)d.Mtot + 1) * g->K + kSlabPad) * sizeof(float) > ws_bytes) --S;

@@ -167,12 +167,13 @@ def data_adapter_unavailable(name, needs):
 
 
 def train_on_stream(E, G, D, stream_fn, n_batches_hint=None, n_epochs=1, l_rate=1e-4, device='cpu',
-                    preprocess=None, attr_keys=(), use_stepper=None, family=None):
+                    preprocess=None, attr_keys=(), use_stepper=None, family=None, capture=True):
     """The training loop of audio_mnist.train / whalecalls.train / esrf_acoustic.train (audio_mnist.py:372-420 etc.)
     over any generator of batch dicts ``{"audio": [B,H,W], <attr>: one-hot ...}``.
 
     Adam(lr, betas=(0.5, 0.9)) for E+G and for D; z ~ N(0,1) sampled on the host like the reference.  On a CUDA device
-    the hand-scheduled ``AliStepper`` is used (``use_stepper``), otherwise the autograd ``ali_step``.
+    the hand-scheduled ``AliStepper`` is used (``use_stepper``; ``capture``: replay the iteration from a HIP graph per
+    batch shape), otherwise the autograd ``ali_step``.
     Returns (E, G, D, optimizer_D, optimizer_E, epoch_scores)."""
     from .training_utils import ali_step
     dev = torch.device(device)
@@ -181,7 +182,7 @@ def train_on_stream(E, G, D, stream_fn, n_batches_hint=None, n_epochs=1, l_rate=
     scores = []
     if use_stepper:
         from ali_hip.step import AliStepper
-        stepper = AliStepper(E, G, D, lr=l_rate, betas=(0.5, 0.9), family=family)
+        stepper = AliStepper(E, G, D, lr=l_rate, betas=(0.5, 0.9), family=family, capture=capture)
         opt_e, opt_d = stepper.opt_eg, stepper.opt_d
     else:
         opt_e = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=l_rate, betas=(0.5, 0.9))

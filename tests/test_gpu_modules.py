@@ -27,11 +27,14 @@ class TieWatch:
 
     The sign of such a pre-activation depends on the order in which its dot product was accumulated -- on the CPU
     (thread count) as much as on the GPU (tile / split-K choice) -- and it switches the derivative between 1 and the
-    negative slope for everything behind it.  Gradients of a case with such an element are compared with the
-    outlier-tolerant criterion of ``grad_close``; cases without one are held to the strict max-abs bound."""
+    negative slope for everything behind it.  A gradient comparison on such a case says nothing, so the module tests
+    only run on cases WITHOUT one: ``tie_free`` re-seeds the inputs until the oracle's forward has none, and the
+    comparison pass itself fails loudly (``strict``) if one shows up anyway.  Every tensor is then held to the plain
+    max-abs bound -- no loosened criterion exists."""
 
-    def __init__(self, *mods):
+    def __init__(self, *mods, strict=False):
         self.ties = 0
+        self.strict = strict
         self.hooks = [m.register_forward_hook(self._hook) for mod in mods for m in mod.modules()
                       if isinstance(m, torch.nn.LeakyReLU)]
 
@@ -45,17 +48,35 @@ class TieWatch:
     def __exit__(self, *exc):
         for h in self.hooks:
             h.remove()
+        if self.strict and exc[0] is None:
+            assert self.ties == 0, f"{self.ties} LeakyReLU inputs within fp32 noise of 0: pick another case (tie_free)"
 
 
-def grad_close(got, ref, rtol=TOL, what="", ties=0):
-    if not ties:
-        return close(got, ref, rtol, what)
-    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
-    assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    err = (got - ref).abs()
-    worst = err.max().item() / (ref.abs().max().item() + 1e-30)
-    l2 = (err.norm() / (ref.norm() + 1e-30)).item()
-    assert worst <= 0.1 and l2 <= 3e-2, f"{what}: max err {worst:.2e} of scale, rel L2 {l2:.2e} ({ties} sign ties)"
+def tie_free(mods, make, run, tries=24):
+    """First ``args = make(variant)`` for which the oracle forward ``run(*args)`` has no LeakyReLU input within fp32
+    summation noise of zero (about one element per million is: large cases need a few draws)."""
+    for v in range(tries):
+        args = make(v)
+        with TieWatch(*mods) as tw, torch.no_grad():
+            run(*args)
+        if tw.ties == 0:
+            return args
+    pytest.fail(f"no tie-free case in {tries} draws")
+
+
+def case_data(family, B, variant=0):
+    """Inputs of a module case; variant 0 is the golden fixture's case (tests/test_oracle_golden.make_module_case)."""
+    if family == "mnist":
+        xs, a = orc.synth_morphomnist(B, seed=3 + 100 * variant)
+        stats = {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"}
+        images, c = orc.mnist_scale_batch(xs, a, stats)
+        z = torch.randn(B, 512, 1, 1, generator=torch.Generator().manual_seed(5 + 100 * variant))
+        return images, c, z
+    return orc.synth_spect_batch(family, B, seed=3 + 100 * variant)
+
+
+def grad_close(got, ref, rtol=TOL, what=""):
+    return close(got, ref, rtol, what)
 
 
 def to_dev(c):
@@ -85,32 +106,35 @@ def paired_models(family="mnist", rescale=True, d=64, B=4):
     return (Eo, Go, Do), (E.cuda(), G.cuda(), D.cuda()), images, c, z
 
 
-def check_param_grads(mod_o, mod_p, what, rtol=TOL, ties=0):
+def check_param_grads(mod_o, mod_p, what, rtol=TOL):
     go = dict(mod_o.named_parameters())
     for k, p in mod_p.named_parameters():
         ref = go[k].grad if go[k].grad is not None else torch.zeros_like(go[k])
         got = p.grad if p.grad is not None else torch.zeros_like(p)
-        grad_close(got, ref, rtol, f"{what}.{k}.grad", ties)
+        grad_close(got, ref, rtol, f"{what}.{k}.grad")
 
 
 def test_mnist_modules_fwd_bwd_vs_oracle():
     import ali_hip
-    (Eo, Go, Do), (E, G, D), images, c, z = paired_models("mnist")
+    (Eo, Go, Do), (E, G, D), _, _, _ = paired_models("mnist")
     gcot = torch.Generator().manual_seed(9)
-    cd = to_dev(c)
+    B = 4
     # Encoder
     Eo.train(), E.train()
-    with TieWatch(Eo) as tw:
+    images, c, _ = tie_free([Eo], lambda v: case_data("mnist", B, v), lambda im, cc, zz: Eo(im, cc))
+    cd = to_dev(c)
+    with TieWatch(Eo, strict=True):
         exo = Eo(images, c)
     w = torch.randn(exo.shape, generator=gcot)
     (exo * w).sum().backward()
     ex = E(images.cuda(), cd)
     close(ex, exo, what="E.out")
     (ex * w.cuda()).sum().backward()
-    check_param_grads(Eo, E, "E", ties=tw.ties)
+    check_param_grads(Eo, E, "E")
     # Generator, grads w.r.t. z too
+    _, _, z = tie_free([Go], lambda v: case_data("mnist", B, v), lambda im, cc, zz: Go(zz, c))
     zo = z.clone().requires_grad_(True)
-    with TieWatch(Go) as tw:
+    with TieWatch(Go, strict=True):
         gzo = Go(zo, c)
     w = torch.randn(gzo.shape, generator=gcot)
     (gzo * w).sum().backward()
@@ -118,29 +142,41 @@ def test_mnist_modules_fwd_bwd_vs_oracle():
     gz = G(zp, cd)
     close(gz, gzo, what="G.out")
     (gz * w.cuda()).sum().backward()
-    grad_close(zp.grad, zo.grad, what="G.gz", ties=tw.ties)
-    check_param_grads(Go, G, "G", ties=tw.ties)
+    grad_close(zp.grad, zo.grad, what="G.gz")
+    check_param_grads(Go, G, "G")
     # Discriminator: eval mode, then train mode with the oracle's masks replayed
     for mode in ("eval", "train"):
         Do.zero_grad(), D.zero_grad()
         Do.train(mode == "train"), D.train(mode == "train")
-        tape = orc.MaskTape()
+        bufs = copy.deepcopy(Do.state_dict())
+
+        def draw(v):
+            Do.load_state_dict(bufs)              # a rejected draw must not leave BatchNorm running-stat updates behind
+            torch.manual_seed(21 + v)
+            return (orc.MaskTape(),)
+
+        def fwd(tape):
+            with orc.use_tape(tape):
+                Do(images, exo.detach(), c)
+
+        (drawn,) = tie_free([Do], draw, fwd)
+        Do.load_state_dict(bufs)
+        tape = orc.MaskTape(replay=drawn.masks)
         xo = images.clone().requires_grad_(True)
         zo = exo.detach().clone().requires_grad_(True)
-        torch.manual_seed(21)
-        with orc.use_tape(tape), TieWatch(Do) as tw:
+        with orc.use_tape(tape), TieWatch(Do, strict=True):
             dlo = Do(xo, zo, c)
         w = torch.randn(dlo.shape, generator=gcot)
         (dlo * w).sum().backward()
         xp = images.clone().cuda().requires_grad_(True)
         zp = exo.detach().clone().cuda().requires_grad_(True)
-        with ali_hip.injected_masks(tape.masks):
+        with ali_hip.injected_masks(drawn.masks):
             dl = D(xp, zp, cd)
         close(dl, dlo, what=f"D.{mode}.out")
         (dl * w.cuda()).sum().backward()
-        grad_close(zp.grad, zo.grad, what=f"D.{mode}.gz", ties=tw.ties)
-        grad_close(xp.grad, xo.grad, what=f"D.{mode}.gx", ties=tw.ties)
-        check_param_grads(Do, D, f"D.{mode}", ties=tw.ties)
+        grad_close(zp.grad, zo.grad, what=f"D.{mode}.gz")
+        grad_close(xp.grad, xo.grad, what=f"D.{mode}.gx")
+        check_param_grads(Do, D, f"D.{mode}")
         for k, v in D.state_dict().items():
             if "running" in k or "num_batches" in k:
                 close(v.float(), Do.state_dict()[k].float(), 1e-5, f"D.{mode}.{k}")
@@ -255,16 +291,16 @@ def test_hip_library_is_loaded_and_mandatory():
         assert "libali_hip.so" in f.read()
 
 
-def _stepper_setup(rescale=True, capture=False, bs=64):
+def _stepper_setup(rescale=True, capture=False, bs=64, n=3):
     from ali_hip.step import AliStepper
     (Eo, Go, Do), (E, G, D), _, _, _ = paired_models("mnist", rescale=rescale)
     for m in (Eo, Go, Do, E, G, D):
         m.train()
-    x, a = orc.synth_morphomnist(3 * bs, seed=1)
+    x, a = orc.synth_morphomnist(n * bs, seed=1)
     stats = {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"}
     batches = []
     g = torch.Generator().manual_seed(123)
-    for i in range(3):
+    for i in range(n):
         images, c = orc.mnist_scale_batch(x[i * bs:(i + 1) * bs], {k: v[i * bs:(i + 1) * bs] for k, v in a.items()},
                                           stats)
         batches.append((images, c, torch.randn(bs, 512, 1, 1, generator=g)))
@@ -280,9 +316,11 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
-@pytest.mark.parametrize("rescale", [True, False])
-def test_hand_scheduled_stepper_vs_oracle(rescale):
+@pytest.mark.parametrize("rescale,bs", [(True, 64), (False, 64), (True, 512), (False, 512)])
+def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
     """AliStepper (no autograd, wasted work skipped, flat Adam kernel) vs the reference iteration, phase by phase.
+    bs=512 is the benched configuration (BASELINE.json configs[1]): its tile / split-K / wgrad-slab choices and the
+    paired 2B = 1024-row Discriminator passes differ from bs=64's.
 
     Adam's first updates are sign-like (+-lr whatever the gradient's size) and a LeakyReLU whose pre-activation is
     ~1e-7 can take the other branch on the GPU, so a handful of weights legitimately move the other way and the
@@ -290,7 +328,7 @@ def test_hand_scheduled_stepper_vs_oracle(rescale):
     BN buffers, Adam moments, step counts) before every phase and each phase is held to rounding level:
     gradients rel-L2 <= 2e-3 (allows such flips; typical 1e-6 -- the per-kernel tests hold the tight bar)."""
     import torch.nn as nn
-    (Eo, Go, Do), (E, G, D), stepper, batches = _stepper_setup(rescale)
+    (Eo, Go, Do), (E, G, D), stepper, batches = _stepper_setup(rescale, bs=bs, n=3 if bs == 64 else 2)
     oe, od = orc.build_optimizers(Eo, Go, Do, "mnist")
     bce = nn.BCEWithLogitsLoss()
     lr = 1e-4
@@ -385,13 +423,15 @@ def test_stepper_three_iterations_free_running():
             assert abs(rp[k].item() - ro[k]) <= 1e-3 * max(1.0, abs(ro[k])), (i, k, rp[k].item(), ro[k])
 
 
-def test_graph_captured_stepper_equals_eager():
-    """HIP-graph replay of the iteration == eager launches (device-side Adam step count and dropout counter)."""
+@pytest.mark.parametrize("bs", [64, 512])
+def test_graph_captured_stepper_equals_eager(bs):
+    """HIP-graph replay of the iteration == eager launches (device-side Adam step count and dropout counter), bit for
+    bit -- also at the benched bs=512, so the eager-vs-oracle checks above carry over to the replayed graph."""
     import ali_hip
     ali_hip.manual_seed(99)
-    _, (E1, G1, D1), eager, batches = _stepper_setup(capture=False)
+    _, (E1, G1, D1), eager, batches = _stepper_setup(capture=False, bs=bs)
     ali_hip.manual_seed(99)
-    _, (E2, G2, D2), graphed, _ = _stepper_setup(capture=True)
+    _, (E2, G2, D2), graphed, _ = _stepper_setup(capture=True, bs=bs)
     outs = []
     for images, c, z in batches:
         r1 = eager.step(images.cuda(), to_dev(c), z.cuda())
@@ -402,13 +442,17 @@ def test_graph_captured_stepper_equals_eager():
             assert r1[k] == r2[k], (k, r1[k], r2[k])
     for (k, v1), (_, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
         assert torch.equal(v1, v2), k
+    assert torch.equal(eager.opt_d.flat, graphed.opt_d.flat) and torch.equal(eager.opt_eg.flat, graphed.opt_eg.flat)
     # Dropout masks differ between iterations (fresh counter every replay)
     assert outs[0][0]["dg"] != outs[1][0]["dg"]
 
 
-def test_stepper_with_one_rank_rccl_group():
-    """The DP wiring (flat-buffer all-reduce over RCCL, 1/world folded into Adam, BN buffer averaging) on a
-    1-rank "nccl" group must reproduce the group-less stepper bit for bit."""
+@pytest.mark.parametrize("capture", [False, True])
+def test_stepper_with_one_rank_rccl_group(capture):
+    """The DP wiring on a 1-rank "nccl" (= RCCL) group: every collective of the schedule is really issued -- the three
+    flat-buffer all-reduces (asynchronous, overlapped with the next segment), the BatchNorm buffer average, and with
+    ``capture`` the one-HIP-graph-per-segment replay with the collectives launched in between -- and, a 1-rank sum
+    being the identity and 1/world = 1, the result must equal the group-less eager stepper bit for bit."""
     import os
     import torch.distributed as dist
     import ali_hip
@@ -419,22 +463,36 @@ def test_stepper_with_one_rank_rccl_group():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         created = True
     try:
+        from ali_hip import dp
         from ali_hip.step import AliStepper
         ali_hip.manual_seed(5)
         _, (E1, G1, D1), plain, batches = _stepper_setup()
         ali_hip.manual_seed(5)
         _, (E2, G2, D2), _, _ = _stepper_setup()
-        grouped = AliStepper(E2, G2, D2, process_group=dist.group.WORLD)
-        grouped.world = 2          # force the collective code path (sum over 1 rank, then average by 1/2 ...)
-        grouped.world = 1          # ... no: keep exact arithmetic; the collectives below run via dp.* directly
-        from ali_hip import dp
-        for images, c, z in batches[:2]:
-            r1 = plain.step(images.cuda(), to_dev(c), z.cuda())
-            r2 = grouped.step(images.cuda(), to_dev(c), z.cuda())
-            dp.allreduce_sum_(grouped.opt_d.grad, dist.group.WORLD)      # RCCL all-reduce on the flat buffer
-            dp.average_buffers_(grouped.bn_buffers, dist.group.WORLD)
-            assert all(r1[k].item() == r2[k].item() for k in r1)
+        grouped = AliStepper(E2, G2, D2, process_group=dist.group.WORLD, capture=capture)
+        assert grouped.dist and grouped.world == 1
+        issued = []
+        real_async = dp.allreduce_sum_async_
+
+        def counting(flat, group=None):
+            issued.append(flat.numel())
+            return real_async(flat, group)
+
+        dp.allreduce_sum_async_ = counting
+        try:
+            for images, c, z in batches:
+                r1 = plain.step(images.cuda(), to_dev(c), z.cuda())
+                r2 = grouped.step(images.cuda(), to_dev(c), z.cuda())
+                assert all(r1[k].item() == r2[k].item() for k in r1)
+        finally:
+            dp.allreduce_sum_async_ = real_async
+        if capture:
+            assert any(k[0] == "seg" for k in grouped._graph), "the segmented graph replay did not run"
+        # 3 all-reduces per iteration (E+G once, D twice), plus the warm-up iteration of the capture
+        assert len(issued) >= 3 * len(batches) and set(issued) == {grouped.opt_eg.n, grouped.opt_d.n}
         assert torch.equal(plain.opt_d.flat, grouped.opt_d.flat) and torch.equal(plain.opt_eg.flat, grouped.opt_eg.flat)
+        for (k, v1), (_, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
+            assert torch.equal(v1, v2), k
     finally:
         if created:
             dist.destroy_process_group()
@@ -446,23 +504,27 @@ SPECT_CASES = [("audio", 8, 2), ("audio", 64, 2), ("whale", 16, 1), ("esrf", 8, 
 @pytest.mark.parametrize("family,d,B", SPECT_CASES)
 def test_spect_modules_fwd_bwd_vs_oracle(family, d, B):
     """audio (128x128), whale (256x256), ESRF (512x512) Encoder / Generator / Discriminator forward + backward on the
-    HIP kernels vs the oracle (same seeded case as tests/golden/modules_<family>_*.npz): Linear+Unflatten as a
-    permuted 1x1 GEMM, 5x5 stride-2 convolutions, 5x5 stride-2 transposed convolutions in 4 sub-pixel phases."""
-    (Eo, Go, Do), (E, G, D), images, c, z = paired_models(family, d=d, B=B)
+    HIP kernels vs the oracle (weights of tests/golden/modules_<family>_*.npz's case; inputs re-drawn until the oracle's
+    forward has no LeakyReLU input at fp32 noise level, see TieWatch): Linear+Unflatten as a permuted 1x1 GEMM, 5x5
+    stride-2 convolutions, 5x5 stride-2 transposed convolutions in 4 sub-pixel phases.  Every output and gradient is
+    held to the strict max-abs bound."""
+    (Eo, Go, Do), (E, G, D), _, _, _ = paired_models(family, d=d, B=B)
     gcot = torch.Generator().manual_seed(9)
-    cd = to_dev(c)
     for m in (Eo, Go, Do, E, G, D):
         m.train()
-    with TieWatch(Eo) as tw:
+    images, c, _ = tie_free([Eo], lambda v: case_data(family, B, v), lambda im, cc, zz: Eo(im, cc))
+    cd = to_dev(c)
+    with TieWatch(Eo, strict=True):
         exo = Eo(images, c)
     w = torch.randn(exo.shape, generator=gcot)
     (exo * w).sum().backward()
     ex = E(images.cuda(), cd)
     close(ex, exo, what="E.out")
     (ex * w.cuda()).sum().backward()
-    check_param_grads(Eo, E, "E", rtol=1e-3, ties=tw.ties)
+    check_param_grads(Eo, E, "E", rtol=1e-3)
+    _, _, z = tie_free([Go], lambda v: case_data(family, B, v), lambda im, cc, zz: Go(zz, c))
     zo = z.clone().requires_grad_(True)
-    with TieWatch(Go) as tw:
+    with TieWatch(Go, strict=True):
         gzo = Go(zo, c)
     w = torch.randn(gzo.shape, generator=gcot)
     (gzo * w).sum().backward()
@@ -470,25 +532,27 @@ def test_spect_modules_fwd_bwd_vs_oracle(family, d, B):
     gz = G(zp, cd)
     close(gz, gzo, what="G.out")
     (gz * w.cuda()).sum().backward()
-    grad_close(zp.grad, zo.grad, rtol=1e-3, what="G.gz", ties=tw.ties)
-    check_param_grads(Go, G, "G", rtol=1e-3, ties=tw.ties)
-    xo = images.clone().requires_grad_(True)
+    grad_close(zp.grad, zo.grad, rtol=1e-3, what="G.gz")
+    check_param_grads(Go, G, "G", rtol=1e-3)
+    # Discriminator: its own image draw (same attributes), the Encoder's code as z input
+    imd, _, _ = tie_free([Do], lambda v: case_data(family, B, v), lambda im, cc, zz: Do(im, exo.detach(), c))
+    xo = imd.clone().requires_grad_(True)
     zo = exo.detach().clone().requires_grad_(True)
-    with TieWatch(Do) as tw:
+    with TieWatch(Do, strict=True):
         dlo = Do(xo, zo, c)
     w = torch.randn(dlo.shape, generator=gcot)
     (dlo * w).sum().backward()
-    xp = images.clone().cuda().requires_grad_(True)
+    xp = imd.clone().cuda().requires_grad_(True)
     zp = exo.detach().clone().cuda().requires_grad_(True)
     dl = D(xp, zp, cd)
     close(dl, dlo, what="D.out")
     (dl * w.cuda()).sum().backward()
-    grad_close(zp.grad, zo.grad, rtol=1e-3, what="D.gz", ties=tw.ties)
-    grad_close(xp.grad, xo.grad, rtol=1e-3, what="D.gx", ties=tw.ties)
-    check_param_grads(Do, D, "D", rtol=1e-3, ties=tw.ties)
+    grad_close(zp.grad, zo.grad, rtol=1e-3, what="D.gz")
+    grad_close(xp.grad, xo.grad, rtol=1e-3, what="D.gx")
+    check_param_grads(Do, D, "D", rtol=1e-3)
 
 
-@pytest.mark.parametrize("family,d,B", [("audio", 8, 4), ("esrf", 4, 2)])
+@pytest.mark.parametrize("family,d,B", [("audio", 8, 4), ("whale", 8, 2), ("esrf", 4, 2)])
 def test_spect_stepper_iteration_vs_oracle(family, d, B):
     """One hand-scheduled iteration of the spectrogram families (no dropout / BN: deterministic given z) vs the
     oracle's ali_step: losses, scores and the Adam update of every parameter."""
