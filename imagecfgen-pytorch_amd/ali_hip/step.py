@@ -96,6 +96,11 @@ class MnistFamily:
         onehots = [c["digit"].float()]
         return idx, cont, onehots
 
+    @staticmethod
+    def used(c):
+        """the entries of an attribute dict the models read (mnist.py:47-51: every key)"""
+        return {k: v for k, v in c.items() if torch.is_tensor(v)}
+
 
 class SpectFamily:
     """Input assembly of the spectrogram models (audio_mnist.py:203-210,250-256,309-318 and the whale / ESRF copies):
@@ -116,6 +121,12 @@ class SpectFamily:
         cont = c[self.cont_key].reshape(B, 1).float().contiguous() if self.cont_key is not None else None
         onehots = [c[k].float() for k in self.cat_keys]
         return idx, cont, onehots
+
+    def used(self, c):
+        """the entries of an attribute dict the models read: callers may pass whole batch dicts with extra keys
+        (finetune_whale_bigan.py:63-64: 'audio', 'path', 'time')"""
+        keys = self.cat_keys + ((self.cont_key,) if self.cont_key is not None else ())
+        return {k: c[k] for k in keys}
 
 
 def family_of(E, G, D):
@@ -579,27 +590,64 @@ class AliStepper:
 
 class FinetuneStepper:
     """Encoder fine-tuning against a frozen Generator, hand scheduled (reference
-    finetune_mnist_bigan.py:64-85, finetune_audio_mnist_bigan.py, finetune_whale_bigan.py with ``--metric mse``):
+    finetune_mnist_bigan.py:64-85, finetune_audio_mnist_bigan.py:62-91, finetune_whale_bigan.py:52-77 with
+    ``--metric mse``):
 
         codes = E(x, a); xr = G(codes, a); loss = mean((x - xr)^2) + mean(codes^2); Adam(E).step()
 
     E runs forward + full backward, G forward + data gradient only (its weight gradients are never used by the
-    reference's optimiser), the two scalar losses and their gradients are O(B*H*W) torch ops.
+    reference's optimiser); the two scalar losses and their gradients are O(B*H*W) elementwise work.  ``a`` may be a
+    whole batch dict with extra keys (the whale script passes it as is).  ``x`` of shape [B,H,W] (the whale script
+    never adds the channel axis) makes ``x - xr`` broadcast to all B*B pairs, exactly as in the reference; [B,1,H,W]
+    is the ordinary per-sample error.  ``capture=True`` replays the step from a HIP graph per input shape.
     ``step`` returns {"rec": mse, "latent": mean(codes^2)} as 0-d device tensors (no host sync)."""
 
-    def __init__(self, E, G, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, family=None):
+    def __init__(self, E, G, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, family=None, capture=False):
         self.E, self.G = E, G
         self.family = family or (SpectFamily(E, G, E) if hasattr(E, "cat_keys") else _mnist_family_eg(E, G))
         self.pE, self.pG = get_plan(E.layers), get_plan(G.layers)
         self.opt_e = FlatGroup(list(E.parameters()), lr, betas, eps)
         self.pE.cache.store.clear()
         self.pE.cache.static = True
+        self.capture = capture
+        self._graphs = {}
 
     @torch.no_grad()
     def step(self, x, a):
+        a = self.family.used(a)
+        if not (self.capture and x.is_cuda):
+            return self._step(x, a)
+        key = (tuple(x.shape), tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(a.items())), self.E.training,
+               self.G.training)
+        ent = self._graphs.get(key)
+        if ent is None:
+            st_x, st_a = x.clone(), {k: v.clone() for k, v in a.items()}
+            snap = [t.clone() for t in (self.opt_e.flat, self.opt_e.m, self.opt_e.v, self.opt_e.step_t)]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._step(st_x, st_a)                     # warm-up outside capture: packs, workspace, plans
+            torch.cuda.current_stream().wait_stream(side)
+            for t, v in zip((self.opt_e.flat, self.opt_e.m, self.opt_e.v, self.opt_e.step_t), snap):
+                t.copy_(v)                                 # the warm-up must not count as a training step
+            self.opt_e.steps = int(self.opt_e.step_t.item())
+            self.pE.cache.refresh()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                res = self._step(st_x, st_a)
+            ent = self._graphs[key] = (graph, st_x, st_a, res)
+        graph, st_x, st_a, res = ent
+        st_x.copy_(x)
+        for k, v in a.items():
+            st_a[k].copy_(v)
+        graph.replay()
+        return res
+
+    def _step(self, x, a):
         fam = self.family
         B = x.shape[0]
         H, W = fam.hw
+        pairwise = x.dim() == 3 and B > 1          # [B,H,W] - [B,1,H,W] broadcasts to [B,B,H,W] (whale script)
         idx, cont, onehots = fam.conditioning(a)
         n_log = 1 + len(fam.e_tables) + (0 if cont is None else cont.shape[1])
         x0 = ops.assemble_planes(x.reshape(B, H, W).float().contiguous(), idx, [t.detach() for t in fam.e_tables],
@@ -615,10 +663,17 @@ class FinetuneStepper:
             feats.append(torch.zeros(B, pad, device=x.device))
         gin = torch.cat(feats, dim=1).reshape(B, 1, 1, -1)
         xr, sG = chain_forward(self.pG, gin, self.G.training, g_log, True)
-        diff = xr.reshape(B, -1) - x.reshape(B, -1).float()
-        rec = diff.square().mean()
+        xf, xrf = x.reshape(B, -1).float(), xr.reshape(B, -1)
+        if pairwise:
+            # mean_{i,j,p} (x_jp - xr_ip)^2 and its gradient 2/(B*P) * (xr_ip - mean_j x_jp)
+            xbar = xf.mean(dim=0, keepdim=True)
+            rec = xrf.square().mean() - 2.0 * (xrf.mean(dim=0) * xbar[0]).mean() + xf.square().mean()
+            g_xr = ((xrf - xbar) * (2.0 / xrf.numel())).reshape(xr.shape).contiguous()
+        else:
+            diff = xrf - xf
+            rec = diff.square().mean()
+            g_xr = (diff * (2.0 / diff.numel())).reshape(xr.shape).contiguous()
         latent = zin.square().mean()
-        g_xr = (diff * (2.0 / diff.numel())).reshape(xr.shape).contiguous()
         g_gin, _ = chain_backward(self.pG, sG, g_xr, g_log, True, need_params=False)
         g_codes = (g_gin.reshape(B, -1)[:, :zin.shape[1]] + zin * (2.0 / zin.numel())).contiguous()
         dst = self.opt_e.grad_views

@@ -9,6 +9,7 @@ on the HIP kernels through ``ali_hip.chain``; CPU tensors run the stock torch op
 """
 from functools import partial
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -166,20 +167,147 @@ def data_adapter_unavailable(name, needs):
     return _Unavailable
 
 
+class WaveformData:
+    """Tensor-in data source with the interface the reference's training loops consume from ``AudioMNISTData`` /
+    ``WhaleCallData`` / ``EsrfStation`` (audio_mnist.py:41-170, whalecalls.py:31-227, esrf_acoustic.py:32-131):
+    ``.data`` (dict, its keys name the attribute columns), ``.stream(batch_size, ...)`` yielding batch dicts whose
+    ``"audio"`` entry is the log-spectrogram ``(Spectrogram(x) + 1e-6).log()`` of the batch's raw waveforms and whose
+    other entries are the (already encoded) attributes.
+
+    The zip / wav / label-table readers of those classes are outside the hot path; what they hand to the loop is
+    exactly this: waveforms [N, L] and per-clip attribute arrays.  The spectrogram is computed per batch ON THE DEVICE
+    by ``ali_hip.spectrogram.SpectrogramFrontEnd`` (CUDA) -- the reference recomputes it with torchaudio every epoch
+    -- or by ``torch.stft`` with torchaudio's parameter mapping (CPU).  ``fuse_spect_to_img(mean, std)`` makes the
+    stream return the standardised, clipped image of ``spect_to_img`` (audio_mnist.py:361-363) from the same kernel.
+    """
+
+    def __init__(self, waveforms, attrs, n_fft, win_length, hop_length=None, pad=0, device="cpu", runs=None,
+                 subjects=None):
+        self.device = torch.device(device)
+        self.wave = torch.as_tensor(waveforms).float().to(self.device)
+        self.data = {"audio": self.wave}
+        self.data.update({k: torch.as_tensor(v).to(self.device) for k, v in attrs.items()})
+        self.runs = None if runs is None else np.asarray(runs).reshape(-1)
+        self.subjects = None if subjects is None else np.asarray(subjects).reshape(-1)
+        self.stft = dict(n_fft=n_fft, win_length=win_length, hop_length=hop_length or win_length // 2, pad=pad)
+        self._front = None
+        self._stats = None
+
+    def fuse_spect_to_img(self, mean, std, stds_kept=3.0):
+        self._stats = (mean.reshape(-1).float(), std.reshape(-1).float(), float(stds_kept))
+
+    def spectrogram(self, wave):
+        """[B, L] -> [B, F, T] log-spectrogram (or the standardised image once ``fuse_spect_to_img`` was called)."""
+        st = self.stft
+        if wave.is_cuda:
+            if self._front is None:
+                from ali_hip.spectrogram import SpectrogramFrontEnd
+                self._front = SpectrogramFrontEnd(st["n_fft"], st["win_length"], st["hop_length"], st["pad"],
+                                                  device=wave.device)
+            if self._stats is None:
+                return self._front(wave)
+            return self._front(wave, self._stats[0], self._stats[1], self._stats[2])
+        x = torch.nn.functional.pad(wave.float(), (st["pad"], st["pad"]))
+        spec = torch.stft(x, st["n_fft"], hop_length=st["hop_length"], win_length=st["win_length"],
+                          window=torch.hann_window(st["win_length"]), center=True, pad_mode="reflect",
+                          normalized=False, onesided=True, return_complex=True).abs().pow(2.0)
+        out = (spec + 1e-6).log()
+        if self._stats is not None:
+            mean, std, k = self._stats
+            out = torch.clip((out - mean.reshape(1, 1, -1)) / (std.reshape(1, 1, -1) + 1e-6), -k, k) / k
+        return out
+
+    def stream(self, batch_size=128, transform=True, shuffle=True, excluded_runs=None, excluded_subjects=None,
+               mode=None):
+        n_all = len(self.wave)
+        keep = np.ones(n_all, dtype=bool)
+        if excluded_runs is not None and len(excluded_runs) and self.runs is not None:
+            keep &= ~np.isin(self.runs, np.asarray(excluded_runs))
+        if excluded_subjects is not None and len(excluded_subjects) and self.subjects is not None:
+            keep &= ~np.isin(self.subjects, np.asarray(excluded_subjects))
+        pool = np.nonzero(keep)[0]
+        order = pool[np.random.permutation(len(pool))] if shuffle else pool
+        for lo in range(0, len(order), batch_size):
+            sel = torch.as_tensor(order[lo:lo + batch_size], device=self.device)
+            batch = {k: v[sel] for k, v in self.data.items()}
+            if transform:
+                batch["audio"] = self.spectrogram(batch["audio"])
+            yield batch
+
+
+def is_data_source(obj):
+    """True for an object with the data-adapter interface (``.data`` and ``.stream``) given where the reference's
+    ``train`` takes dataset paths."""
+    return hasattr(obj, "stream") and hasattr(obj, "data")
+
+
+def spectrogram_statistics(stream_fn, device):
+    """The statistics pass in front of every spectrogram training loop (audio_mnist.py:347-359): per-last-index mean
+    and standard deviation of the log-spectrograms, averaged over batches."""
+    mean, ss, n = 0, 0, 0
+    for batch in stream_fn():
+        n += 1
+        mean = mean + batch["audio"].mean(dim=(0, 1)).reshape((1, 1, -1))
+        ss = ss + batch["audio"].square().mean(dim=(0, 1)).reshape((1, 1, -1))
+    mean = (mean / n).float().to(device)
+    std = torch.sqrt((ss / n).float().to(device) - mean.square())
+    return mean, std, n
+
+
+def run_training(E, G, D, data, stream_kwargs, attr_keys, n_epochs, l_rate, device, attr_cast=None,
+                 checkpoint_every=None, checkpoint_path=None, capture=True):
+    """What ``audio_mnist.train`` / ``whalecalls.train`` / ``esrf_acoustic.train`` do once the dataset object exists
+    (audio_mnist.py:343-420, whalecalls.py:426-499, esrf_acoustic.py:298-379): statistics pass, ``spect_to_img``,
+    ALI iterations."""
+    stream = lambda: data.stream(**stream_kwargs)  # noqa: E731
+    mean, std, _ = spectrogram_statistics(stream, device)
+    if hasattr(data, "fuse_spect_to_img"):
+        data.fuse_spect_to_img(mean, std, 3.0)          # standardise + clip inside the spectrogram kernel
+        prep = None
+    else:
+        prep = lambda s: torch.clip((s - mean) / (std + 1e-6), -3, 3) / 3.0  # noqa: E731
+    E, G, D, oD, oE, _ = train_on_stream(E, G, D, stream, n_epochs=n_epochs, l_rate=l_rate, device=device,
+                                         preprocess=prep, attr_keys=attr_keys, attr_cast=attr_cast,
+                                         checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path,
+                                         capture=capture)
+    return E, G, D, oD, oE
+
+
+def save_checkpoint(path, E, G, D, stepper=None, opt_e=None, opt_d=None):
+    """State-dict checkpoint in the reference's format (``{E,G,D}_state_dict``: what ``mnist.load_model`` and the audio
+    callers read, mnist.py:302-313, finetune_audio_mnist_bigan.py:57-61) plus both Adam states, so that training can
+    resume (the reference never saves optimiser state).  Written to a temporary name first, then renamed."""
+    import os
+    if stepper is not None:
+        sd = stepper.state_dict()
+    else:
+        sd = {f"{n}_state_dict": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+              for n, m in (("E", E), ("G", G), ("D", D))}
+        if opt_e is not None:
+            sd["optimizer_E"], sd["optimizer_D"] = opt_e.state_dict(), opt_d.state_dict()
+    tmp = f"{path}.tmp"
+    torch.save(sd, tmp)
+    os.replace(tmp, path)
+
+
 def train_on_stream(E, G, D, stream_fn, n_batches_hint=None, n_epochs=1, l_rate=1e-4, device='cpu',
-                    preprocess=None, attr_keys=(), use_stepper=None, family=None, capture=True):
+                    preprocess=None, attr_keys=(), use_stepper=None, family=None, capture=True, attr_cast=None,
+                    checkpoint_every=None, checkpoint_path=None):
     """The training loop of audio_mnist.train / whalecalls.train / esrf_acoustic.train (audio_mnist.py:372-420 etc.)
     over any generator of batch dicts ``{"audio": [B,H,W], <attr>: one-hot ...}``.
 
     Adam(lr, betas=(0.5, 0.9)) for E+G and for D; z ~ N(0,1) sampled on the host like the reference.  On a CUDA device
     the hand-scheduled ``AliStepper`` is used (``use_stepper``; ``capture``: replay the iteration from a HIP graph per
-    batch shape), otherwise the autograd ``ali_step``.
+    batch shape), otherwise the autograd ``ali_step``.  ``attr_cast``: dtype the attributes are cast to (the reference
+    uses ``.float()``, whalecalls.py:455 ``.int()``).  ``checkpoint_every`` (epochs) + ``checkpoint_path``: periodic
+    resumable state-dict checkpoints (``save_checkpoint``).
     Returns (E, G, D, optimizer_D, optimizer_E, epoch_scores)."""
     from .training_utils import ali_step
     dev = torch.device(device)
     if use_stepper is None:
         use_stepper = dev.type == "cuda"
     scores = []
+    stepper = None
     if use_stepper:
         from ali_hip.step import AliStepper
         stepper = AliStepper(E, G, D, lr=l_rate, betas=(0.5, 0.9), family=family, capture=capture)
@@ -189,7 +317,8 @@ def train_on_stream(E, G, D, stream_fn, n_batches_hint=None, n_epochs=1, l_rate=
         opt_d = torch.optim.Adam(D.parameters(), lr=l_rate, betas=(0.5, 0.9))
     gan_loss = nn.BCEWithLogitsLoss()
     H, W = E.image_hw
-    for _ in range(n_epochs):
+    cast = attr_cast or torch.float32
+    for epoch in range(n_epochs):
         for m in (D, E, G):
             m.train()
         d_score = torch.zeros((), device=dev)
@@ -197,7 +326,7 @@ def train_on_stream(E, G, D, stream_fn, n_batches_hint=None, n_epochs=1, l_rate=
         n = 0
         for batch in stream_fn():
             images = batch["audio"].reshape((-1, 1, H, W)).float().to(dev)
-            c = {k: torch.clone(batch[k]).float().to(dev) for k in attr_keys}
+            c = {k: torch.clone(batch[k]).to(cast).to(dev) for k in attr_keys}
             if preprocess is not None:
                 images = preprocess(images)
             z_mean = torch.zeros((len(images), LATENT_DIM, 1, 1)).float()
@@ -211,4 +340,6 @@ def train_on_stream(E, G, D, stream_fn, n_batches_hint=None, n_epochs=1, l_rate=
             n += 1
         scores.append((d_score.item() / max(n, 1), eg_score.item() / max(n, 1)))
         print(*scores[-1])
+        if checkpoint_every and checkpoint_path and (epoch + 1) % checkpoint_every == 0:
+            save_checkpoint(checkpoint_path, E, G, D, stepper, opt_e, opt_d)
     return E, G, D, opt_d, opt_e, scores

@@ -65,29 +65,31 @@ class Discriminator(_Family, _spect.SpectDiscriminator):
         self.dxz = _spect.dxz_stack()
 
 
-def train(path_to_zip: str,
+STFT = dict(n_fft=255, win_length=128, pad=96)     # AudioMNISTData.audio_to_spectrogram (reference :59-61)
+
+
+def train(path_to_zip,
           n_epochs=200,
           l_rate=1e-4,
           device='cpu',
           save_images_every=2,
           batch_size=128,
-          image_output_path=''):
-    """Reference signature (:321-327).  Needs the AudioMNIST zip + torchaudio through ``AudioMNISTData``; the loop
-    itself (statistics pass, spect_to_img standardisation :347-366, ALI iterations :376-420) is ``train_on_stream``."""
+          image_output_path='',
+          checkpoint_every=None,
+          checkpoint_path=None):
+    """Reference signature (:321-327) and loop (:343-420): statistics pass over the training stream, ``spect_to_img``
+    standardisation, ALI iterations with Adam betas (0.5, 0.9).
+
+    ``path_to_zip`` is either the AudioMNIST zip (needs the reference's ``AudioMNISTData`` reader: torchaudio +
+    librosa, not part of this package -- raises ImportError) or a data source with the adapter's interface, e.g.
+    ``_spect.WaveformData(waveforms, attrs, **STFT, device=device, runs=...)``: then the whole loop, spectrograms
+    included, runs on the device.  The demo-image / wav dump of the reference (:422-480, matplotlib + Griffin-Lim) is
+    not part of the path."""
     E, G, D = Encoder().to(device), Generator().to(device), Discriminator().to(device)
     for m in (E, G, D):
         m.apply(init_weights)
-    data = AudioMNISTData(path_to_zip, device=device)     # raises ImportError here (adapter out of scope)
-    stream = lambda: data.stream(batch_size=batch_size, excluded_runs=VALIDATION_RUNS)  # noqa: E731
-    mean, ss, n = 0, 0, 0
-    for batch in stream():
-        n += 1
-        mean = mean + batch["audio"].mean(dim=(0, 1)).reshape((1, 1, -1))
-        ss = ss + batch["audio"].square().mean(dim=(0, 1)).reshape((1, 1, -1))
-    mean = (mean / n).float().to(device)
-    std = torch.sqrt((ss / n).float().to(device) - mean.square())
-    prep = lambda s: torch.clip((s - mean) / (std + 1e-6), -3, 3) / 3.0  # noqa: E731
+    data = path_to_zip if _spect.is_data_source(path_to_zip) else AudioMNISTData(path_to_zip, device=device)
     keys = [k for k in data.data if k in ATTRIBUTE_DIMS]
-    E, G, D, oD, oE, _ = _spect.train_on_stream(E, G, D, stream, n_epochs=n_epochs, l_rate=l_rate, device=device,
-                                                preprocess=prep, attr_keys=keys)
-    return E, G, D, oD, oE
+    return _spect.run_training(E, G, D, data, dict(batch_size=batch_size, excluded_runs=VALIDATION_RUNS), keys,
+                               n_epochs, l_rate, device, checkpoint_every=checkpoint_every,
+                               checkpoint_path=checkpoint_path)

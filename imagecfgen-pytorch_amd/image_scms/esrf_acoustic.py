@@ -57,8 +57,11 @@ class Discriminator(_Family, _spect.SpectDiscriminator):
         self.dxz = _spect.dxz_stack()
 
 
-def train(path_to_wavs: str,
-          path_to_labels: str,
+STFT = dict(n_fft=1023, win_length=256, hop_length=79, pad=200)   # EsrfStation.audio_to_spectrogram (reference :36-39)
+
+
+def train(path_to_wavs,
+          path_to_labels: str = None,
           n_epochs: int = 200,
           l_rate: float = 1e-4,
           device: str = 'cpu',
@@ -66,17 +69,23 @@ def train(path_to_wavs: str,
           batch_size: int = 64,
           image_output_path: str = '',
           validation_split=0.2,
-          start_model_path=None):
-    """Reference signature (:263-272).  ``start_model_path`` warm-starts from a pickled-module checkpoint
-    (:280-284; optimiser state is not restored, as in the reference)."""
+          start_model_path=None,
+          checkpoint_every=None,
+          checkpoint_path=None):
+    """Reference signature (:263-272) and loop (:298-379).  ``start_model_path`` warm-starts from a pickled-module
+    checkpoint (:280-284; optimiser state is not restored, as in the reference).  ``path_to_wavs`` may be a data
+    source with the adapter's interface (``_spect.WaveformData(..., **STFT)``) instead of the wav directory, which
+    needs the reference's ``EsrfStation`` reader (torchaudio, pandas label tables; raises ImportError here)."""
     E, G, D = Encoder().to(device), Generator().to(device), Discriminator().to(device)
     for m in (E, G, D):
         m.apply(init_weights)
     if start_model_path is not None:
         ckpt = torch.load(start_model_path, map_location=device, weights_only=False)
         E, G, D = ckpt["E"].to(device), ckpt["G"].to(device), ckpt["D"].to(device)
-    data = EsrfStation(path_to_wavs, path_to_labels, device=device)   # raises ImportError (adapter out of scope)
-    stream = lambda: data.stream(batch_size=batch_size)  # noqa: E731
-    E, G, D, oD, oE, _ = _spect.train_on_stream(E, G, D, stream, n_epochs=n_epochs, l_rate=l_rate, device=device,
-                                                attr_keys=tuple(ATTRIBUTE_DIMS))
-    return E, G, D, oD, oE
+    if _spect.is_data_source(path_to_wavs):
+        data = path_to_wavs
+    else:
+        data = EsrfStation(path_to_wavs, path_to_labels, device=device, validation_split=validation_split)
+    return _spect.run_training(E, G, D, data, dict(batch_size=batch_size, mode='train'), tuple(ATTRIBUTE_DIMS),
+                               n_epochs, l_rate, device, checkpoint_every=checkpoint_every,
+                               checkpoint_path=checkpoint_path)

@@ -162,8 +162,12 @@ def train(x_train: torch.Tensor,
           image_output_path='',
           batch_size=64,
           d_updates_per_g_update=1,
-          use_stepper=None):
+          use_stepper=None,
+          checkpoint_every=None,
+          checkpoint_path=None):
     """Same signature, RNG order and return value as the reference's train (mnist.py:157-299).
+    ``checkpoint_every`` (epochs) + ``checkpoint_path``: periodic resumable checkpoints in the state-dict format
+    ``load_model`` reads, plus both Adam states (the reference only saves at the end, from its caller).
 
     On a CUDA device the iteration runs on the hand-scheduled ``AliStepper`` (HIP-graph replay; ``use_stepper=False``
     keeps the autograd schedule on the same kernels); the two returned optimisers are then its flat Adam groups
@@ -209,6 +213,9 @@ def train(x_train: torch.Tensor,
 
         if save_images_every and (epoch + 1) % save_images_every == 0 and x_test is not None:
             _save_demo(E, G, D, x_test, a_test, attr_stats, device, epoch, image_output_path)
+        if checkpoint_every and checkpoint_path and (epoch + 1) % checkpoint_every == 0:
+            from ._spect import save_checkpoint
+            save_checkpoint(checkpoint_path, E, G, D, stepper, optimizer_E, optimizer_D)
     return E, G, D, optimizer_D, optimizer_E
 
 

@@ -56,22 +56,33 @@ class Discriminator(_Family, _spect.SpectDiscriminator):
         self.dxz = _spect.dxz_stack()
 
 
+STFT = dict(n_fft=511, win_length=128, hop_length=24, pad=64)     # WhaleCallData.audio_to_spectrogram (reference :52-55)
+
+
 def train(nocall_directory,
-          gunshot_directory,
-          upcall_directory,
+          gunshot_directory=None,
+          upcall_directory=None,
           n_epochs=200,
           l_rate=1e-4,
           device='cpu',
           save_images_every=2,
           batch_size=32,
           image_output_path='',
-          filter_length=None):
-    """Reference signature (:390-399); needs the NARW recordings + torchaudio through ``WhaleCallData``."""
+          filter_length=None,
+          checkpoint_every=None,
+          checkpoint_path=None):
+    """Reference signature (:390-399) and loop (:426-499): statistics pass, ``spect_to_img``, BiGAN iterations with
+    the attributes cast to int (:455).  ``nocall_directory`` may be a data source with the adapter's interface
+    (``_spect.WaveformData(..., **STFT)``) instead of the three NARW recording directories, which need the reference's
+    ``WhaleCallData`` reader (torchaudio, scipy wav/mat files; raises ImportError here)."""
     E, G, D = Encoder().to(device), Generator().to(device), Discriminator().to(device)
     for m in (E, G, D):
         m.apply(init_weights)
-    data = WhaleCallData(nocall_directory, gunshot_directory, upcall_directory, device=device)  # raises ImportError
-    stream = lambda: data.stream(batch_size=batch_size)  # noqa: E731
-    E, G, D, oD, oE, _ = _spect.train_on_stream(E, G, D, stream, n_epochs=n_epochs, l_rate=l_rate, device=device,
-                                                attr_keys=_KEYS)
-    return E, G, D, oD, oE
+    if _spect.is_data_source(nocall_directory):
+        data = nocall_directory
+    else:
+        data = WhaleCallData(nocall_directory, gunshot_directory, upcall_directory, device=device,
+                             filter_length=filter_length)
+    return _spect.run_training(E, G, D, data, dict(batch_size=batch_size), _KEYS, n_epochs, l_rate, device,
+                               attr_cast=torch.int32, checkpoint_every=checkpoint_every,
+                               checkpoint_path=checkpoint_path)

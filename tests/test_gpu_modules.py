@@ -333,12 +333,27 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
     bce = nn.BCEWithLogitsLoss()
     lr = 1e-4
 
-    def check_update(mods_o, mods_p, before, what):
+    def check_update(mods_o, mods_p, before, g_ref, what):
+        """Adam's first steps are sign-like: +-lr whatever the gradient's size.  An element whose gradient is at the
+        gradients' noise level (|g| of the order of the GPU-vs-CPU difference: a summation-order effect, or the
+        one-sample contribution of a LeakyReLU input at fp32 noise level -- at bs=512 every pass has dozens) may step
+        the other way; every element with a gradient clearly above that level must take the oracle's step."""
         wo = torch.cat([p.detach().reshape(-1).double() for m in mods_o for p in m.parameters()])
         wp = torch.cat([p.detach().reshape(-1).double().cpu() for m in mods_p for p in m.parameters()])
         err = ((wp - before) - (wo - before)).abs()
-        assert (err > 0.05 * lr).double().mean().item() < 1e-3, what
+        assert err.max().item() <= 2.2 * lr, (what, err.max().item())
         assert err.mean().item() <= 0.005 * lr, (what, err.mean().item())
+        assert (err > 0.05 * lr).double().mean().item() < 3e-3, what
+        off = n_big = bad_big = 0
+        for m in mods_o:
+            for p in m.parameters():
+                n = p.numel()
+                g = g_ref[off:off + n]
+                big = g.abs() > 0.05 * g.pow(2).mean().sqrt()
+                n_big += int(big.sum())
+                bad_big += int((err[off:off + n][big] > 0.05 * lr).sum())
+                off += n
+        assert bad_big <= 1e-4 * n_big, (what, bad_big, n_big)
 
     def weights(mods):
         return torch.cat([p.detach().reshape(-1).double() for m in mods for p in m.parameters()])
@@ -362,7 +377,7 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
             stepper._phase_eg(cx)
         assert abs(cx["out"]["loss_eg"].item() - l_eg.item()) <= 1e-5 * max(1, abs(l_eg.item()))
         assert _rel(stepper.opt_eg.grad.double().cpu(), g_eg) <= 2e-3, (i, "EG grads")
-        check_update((Eo, Go), (E, G), w_eg, f"EG update {i}")
+        check_update((Eo, Go), (E, G), w_eg, g_eg, f"EG update {i}")
         # ---- phase 2 (mnist.py:232-236) from the oracle's post-EG state
         stepper.load_state(Eo, Go, Do, oe, od)
         n0 = len(tape.masks)
@@ -378,7 +393,7 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
             stepper._phase_d_real(cx)
         assert abs(cx["out"]["loss_d_real"].item() - l_dr.item()) <= 1e-5 * max(1, abs(l_dr.item()))
         assert _rel(stepper.opt_d.grad.double().cpu(), g_d) <= 2e-3, (i, "D real grads")
-        check_update((Do,), (D,), w_d, f"D real update {i}")
+        check_update((Do,), (D,), w_d, g_d, f"D real update {i}")
         # ---- phase 3 (mnist.py:237-241)
         stepper.load_state(Eo, Go, Do, oe, od)
         n0 = len(tape.masks)
@@ -393,7 +408,7 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
             stepper._phase_d_fake(cx)
         assert abs(cx["out"]["loss_d_fake"].item() - l_df.item()) <= 1e-5 * max(1, abs(l_df.item()))
         assert _rel(stepper.opt_d.grad.double().cpu(), g_d) <= 2e-3, (i, "D fake grads")
-        check_update((Do,), (D,), w_d, f"D fake update {i}")
+        check_update((Do,), (D,), w_d, g_d, f"D fake update {i}")
         # ---- phase 4 (mnist.py:243-248)
         stepper.load_state(Eo, Go, Do, oe, od)
         n0 = len(tape.masks)

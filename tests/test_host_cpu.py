@@ -105,3 +105,69 @@ def test_product_spect_modules_match_oracle_on_cpu(family, modname, d, B):
     assert torch.equal(G(z, a), Go(z, a))
     assert torch.equal(D(images, z, a), Do(images, z, a))
     assert torch.equal(G(z.reshape(B, 512), a), Go(z, a))       # z may be [B,512] (reference audio_mnist.py:251)
+
+
+def test_audio_train_entry_point_matches_oracle_loop_on_cpu(tmp_path):
+    """``audio_mnist.train`` (reference audio_mnist.py:321-420) fed a tensor data source on the CPU: statistics pass,
+    spect_to_img, two ALI iterations at the reference width d=64 -- against the same statements executed with the
+    oracle's modules and ``ali_step`` (bit for bit: CPU tensors run the stock torch ops of the same sub-modules).
+    The checkpoint it writes is the state-dict format the audio callers read (finetune_audio_mnist_bigan.py:57-61)."""
+    import image_scms.audio_mnist as pm
+    from image_scms import _spect
+    n, bs = 4, 2
+    g = torch.Generator().manual_seed(8)
+    wave = torch.randn(n, 8000, generator=g)
+    attrs = {k: torch.nn.functional.one_hot(torch.randint(0, v, (n,), generator=g), v).float()
+             for k, v in pm.ATTRIBUTE_DIMS.items()}
+    runs = np.array([1, 2, 38, 3])                       # run 38 is a validation run: excluded from training
+    data = _spect.WaveformData(wave, attrs, **pm.STFT, device="cpu", runs=runs)
+    ck = tmp_path / "audio.tar"
+    torch.manual_seed(3)
+    np.random.seed(3)
+    E, G, D, oD, oE = pm.train(data, n_epochs=1, device="cpu", batch_size=bs, save_images_every=None,
+                               checkpoint_every=1, checkpoint_path=str(ck))
+    # ---- the same, restated with the oracle
+    torch.manual_seed(3)
+    np.random.seed(3)
+    Eo, Go, Do = orc.build_models("audio", 64)
+    oe, od = orc.build_optimizers(Eo, Go, Do, "audio")
+    ref = _spect.WaveformData(wave, attrs, **pm.STFT, device="cpu", runs=runs)
+    kw = dict(batch_size=bs, excluded_runs=pm.VALIDATION_RUNS)
+    mean, ss, nb = 0, 0, 0
+    for batch in ref.stream(**kw):
+        nb += 1
+        mean = mean + batch["audio"].mean(dim=(0, 1)).reshape((1, 1, -1))
+        ss = ss + batch["audio"].square().mean(dim=(0, 1)).reshape((1, 1, -1))
+    mean, ss = (mean / nb).float(), (ss / nb).float()
+    std = torch.sqrt(ss - mean.square())
+    assert nb == 2
+    for m in (Eo, Go, Do):
+        m.train()
+    for batch in ref.stream(**kw):
+        images = batch["audio"].reshape((-1, 1, 128, 128)).float()
+        c = {k: torch.clone(batch[k]).float() for k in ref.data if k in pm.ATTRIBUTE_DIMS}
+        images = torch.clip((images - mean) / (std + 1e-6), -3, 3) / 3.0
+        zm = torch.zeros((len(images), 512, 1, 1)).float()
+        z = torch.normal(zm, zm + 1)
+        orc.ali_step(Eo, Go, Do, oe, od, images, c, z)
+    assert orc.weights_digest(E, G, D) == orc.weights_digest(Eo, Go, Do)
+    sd = torch.load(ck)
+    E2 = pm.Encoder()
+    E2.load_state_dict(sd["E_state_dict"])
+    assert orc.weights_digest(E2) == orc.weights_digest(Eo)
+    assert sd["optimizer_D"]["state"][0]["step"] == 4
+
+
+def test_mnist_checkpoint_and_load_model_on_cpu(tmp_path):
+    """mnist.train(checkpoint_every=...) -> mnist.load_model (reference mnist.py:302-313) round trip."""
+    import image_scms.mnist as pm
+    x, a = orc.synth_morphomnist(64, seed=2)
+    torch.manual_seed(2)
+    np.random.seed(2)
+    ck = tmp_path / "m.tar"
+    E, G, D, _, _ = pm.train(x, a, n_epochs=1, save_images_every=None, batch_size=32, checkpoint_every=1,
+                             checkpoint_path=str(ck))
+    E2, G2, D2, raw = pm.load_model(str(ck), return_raw=True)
+    assert orc.weights_digest(E2, G2, D2) == orc.weights_digest(E, G, D)
+    assert set(raw) >= {"E_state_dict", "G_state_dict", "D_state_dict", "optimizer_E", "optimizer_D"}
+    assert isinstance(pm.load_model(str(ck)), tuple) and len(pm.load_model(str(ck))) == 3
