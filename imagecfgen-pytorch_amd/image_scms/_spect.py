@@ -250,7 +250,10 @@ def spectrogram_statistics(stream_fn, device):
         mean = mean + batch["audio"].mean(dim=(0, 1)).reshape((1, 1, -1))
         ss = ss + batch["audio"].square().mean(dim=(0, 1)).reshape((1, 1, -1))
     mean = (mean / n).float().to(device)
-    std = torch.sqrt((ss / n).float().to(device) - mean.square())
+    # E[X^2] - E[X]^2 in fp32 cancels catastrophically where a frame is (nearly) constant -- the all-zero frames of the
+    # ``pad`` margin -- and the reference's sqrt then returns NaN or a rounding artefact; clamped at 0 here (the only
+    # departure from audio_mnist.py:357-359: a NaN column would poison every image of the run)
+    std = torch.sqrt(torch.clamp_min((ss / n).float().to(device) - mean.square(), 0.0))
     return mean, std, n
 
 

@@ -62,9 +62,12 @@ def test_finetune_stepper_audio_state_dict_flavour(capture):
     lr, steps = 1e-4, 3
     rec, lat = _reference_finetune(Eo, Go, images, c, lr, steps)
     ft = FinetuneStepper(E, G, lr=lr, capture=capture)
-    out = [ft.step(images.cuda(), to_dev(c)) for _ in range(steps)]
-    np.testing.assert_allclose([o["rec"].item() for o in out], rec, rtol=2e-4)
-    np.testing.assert_allclose([o["latent"].item() for o in out], lat, rtol=2e-4)
+    out = []
+    for _ in range(steps):                               # (a replayed graph returns the same output tensors)
+        r = ft.step(images.cuda(), to_dev(c))
+        out.append((r["rec"].item(), r["latent"].item()))
+    np.testing.assert_allclose([o[0] for o in out], rec, rtol=2e-4)
+    np.testing.assert_allclose([o[1] for o in out], lat, rtol=2e-4)
     _check_encoder_update(Eo, E, before, lr, steps)
     if capture:
         assert len(ft._graphs) == 1
@@ -86,9 +89,12 @@ def test_finetune_stepper_whale_whole_batch_dict(capture):
     E.train(), G.eval()
     ft = FinetuneStepper(E, G, lr=lr, capture=capture)
     dev_batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
-    out = [ft.step(x.cuda(), dev_batch) for _ in range(steps)]
-    np.testing.assert_allclose([o["rec"].item() for o in out], rec, rtol=2e-4)
-    np.testing.assert_allclose([o["latent"].item() for o in out], lat, rtol=2e-4)
+    out = []
+    for _ in range(steps):
+        r = ft.step(x.cuda(), dev_batch)
+        out.append((r["rec"].item(), r["latent"].item()))
+    np.testing.assert_allclose([o[0] for o in out], rec, rtol=2e-4)
+    np.testing.assert_allclose([o[1] for o in out], lat, rtol=2e-4)
     _check_encoder_update(Eo, E, before, lr, steps)
 
 
@@ -143,13 +149,18 @@ def test_waveform_data_stream_vs_cpu_restatement(mod_name, L):
         m_ref = m_ref + ref[lo:lo + bs].mean(dim=(0, 1)).reshape(1, 1, -1)
         s_ref = s_ref + ref[lo:lo + bs].square().mean(dim=(0, 1)).reshape(1, 1, -1)
     m_ref, s_ref = m_ref / nb, s_ref / nb
-    std_ref = torch.sqrt(s_ref - m_ref.square())
+    std_ref = torch.sqrt(torch.clamp_min(s_ref - m_ref.square(), 0.0))
     close(mean, m_ref, 1e-5, "spect_mean")
-    close(std, std_ref, 1e-4, "spect_std")
+    # frames inside the zero ``pad`` margin are constant (log 1e-6): their variance is pure fp32 cancellation noise
+    # in the reference's E[X^2] - E[X]^2 formula -- compared only where the variance is real
+    real = (std_ref.reshape(-1) > 0.05)
+    assert real.sum() >= W - 8 and torch.isfinite(std).all()
+    close(std.reshape(-1).cpu()[real], std_ref.reshape(-1)[real], 1e-4, "spect_std")
     data.fuse_spect_to_img(mean, std)
     img = torch.cat([b["audio"] for b in stream()]).cpu()
+    assert torch.isfinite(img).all() and img.abs().max() <= 1.0
     img_ref = torch.clip((ref - m_ref) / (std_ref + 1e-6), -3, 3) / 3.0
-    close(img, img_ref, 2e-4, "spect_to_img")
+    close(img[..., real], img_ref[..., real], 2e-4, "spect_to_img")
 
 
 @pytest.mark.parametrize("mod_name,L,n,bs", [("audio_mnist", 8000, 6, 4), ("whalecalls", 6000, 4, 2),
