@@ -320,6 +320,8 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
     cur = x
     c_log = c_log_in
     folded = None        # mask of the coming stage, already applied by the previous stage's GEMM epilogue
+    early = None         # mask of the coming stage, requested early (its BatchNorm statistics needed it), not applied
+    bn_part = None       # (partials, slots) of the coming stage's BatchNorm, left by the previous stage's GEMM epilogue
     for si, st in enumerate(plan.stages):
         B, H, W, Cp = cur.shape
         rows = H * W
@@ -329,8 +331,10 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
         mask_applied = folded is not None
         if mask_applied:
             mask, folded = folded, None
+        elif early is not None:
+            mask, early = early, None
         for kind, arg in st.pre:
-            if kind == "drop" and training and not mask_applied:
+            if kind == "drop" and training and mask is None:
                 mask = _dropout.next_mask(B, c_log, arg, cur.device, Cp)
             elif kind == "bn":
                 bn = arg
@@ -343,35 +347,50 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             mask_in = mask if kinds == ["drop", "bn"] else None
             mask_post = mask if kinds == ["bn", "drop"] else None
             use_batch = training or bn.running_mean is None
-            if groups == 1:
-                st4 = ops.bn_stats(cur, mask_in, B, rows, Cp, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                                   bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch)
-                if use_batch and bn.num_batches_tracked is not None:
-                    _count_batch(bn)
-                t = ops.bn_apply(cur, st4, mask_in, mask_post, B, rows, Cp)
-            else:       # batched passes: per-pass statistics / running-stat updates, one launch each
+            momentum = bn.momentum if bn.momentum is not None else 0.1
+            if bn_part is not None:     # batch statistics from the partial sums the producing conv left behind
+                part, slots = bn_part
+                bn_part = None
+                stg = ops.bn_stats_from_partials(part, slots, groups, Cp, (B // groups) * rows, bn.weight.detach(),
+                                                 bn.bias.detach(), bn.running_mean, bn.running_var, momentum, bn.eps)
+            else:                       # per-pass statistics / running-stat updates, one launch for all passes
                 stg = ops.bn_stats(cur, mask_in, B, rows, Cp, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                                   bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps, use_batch,
-                                   groups=groups)
-                if use_batch and bn.num_batches_tracked is not None:
-                    for _ in range(groups):
-                        _count_batch(bn)
-                t = ops.bn_apply(cur, stg, mask_in, mask_post, B, rows, Cp, groups=groups)
-                st4 = [stg[gi] for gi in range(groups)]
-            sv.bn_stats = st4
+                                   bn.running_var, momentum, bn.eps, use_batch, groups=groups)
+            if use_batch and bn.num_batches_tracked is not None:
+                for _ in range(groups):
+                    _count_batch(bn)
+            t = ops.bn_apply(cur, stg, mask_in, mask_post, B, rows, Cp, groups=groups)
+            sv.bn_stats = stg if groups == 1 else [stg[gi] for gi in range(groups)]
         elif mask is not None and not mask_applied:
             t = ops.rowmask_mul(cur, mask, B, rows, Cp)
         out_shape = _out_shape(st, B, H, W, Cp)
         g = _geom(st, (B, H, W, Cp), out_shape)
         y = torch.empty(out_shape, dtype=torch.float32, device=cur.device)
+        nxt = plan.stages[si + 1] if si + 1 < len(plan.stages) else None
+        nk = [p[0] for p in nxt.pre] if nxt is not None else []
+        plain_gemm = st.kind in ("conv", "convT") and not _is_tconv1(st, Cp) and not _scatter_fwd(st, Cp)
         # A lone Dropout2d in front of the next stage multiplies this stage's output by a per-(sample, channel)
         # mask: the GEMM epilogue does it (act(.)*mask), so y is stored masked.  LeakyReLU'(y) only needs the sign
         # of y, which the kept entries preserve and the dropped ones do not need (their gradient is masked to 0).
-        nxt = plan.stages[si + 1] if si + 1 < len(plan.stages) else None
-        if (training and nxt is not None and [p[0] for p in nxt.pre] == ["drop"] and st.act in (ACT_NONE, ACT_LEAKY)
-                and st.kind in ("conv", "convT") and not _is_tconv1(st, Cp)):
+        if (training and nk == ["drop"] and st.act in (ACT_NONE, ACT_LEAKY) and st.kind in ("conv", "convT")
+                and not _is_tconv1(st, Cp)):
             folded = _dropout.next_mask(B, out_shape[3], nxt.pre[0][1], cur.device, out_shape[3])
-        ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope, mask=folded)
+        # A BatchNorm behind this conv: its batch statistics are column sums of this stage's output -- accumulated
+        # per M-tile by the GEMM epilogue (times the Dropout2d mask that may sit in between), no extra pass
+        bn_fwd = None
+        if "bn" in nk and st.kind == "conv" and plain_gemm and folded is None:
+            nbn = [a for k, a in nxt.pre if k == "bn"][0]
+            if training or nbn.running_mean is None:
+                if training and nk == ["drop", "bn"]:
+                    early = _dropout.next_mask(B, out_shape[3], nxt.pre[0][1], cur.device, out_shape[3])
+                slots, tile_rows, pixel_major = ops.conv_mtiles(g, 0)
+                rows_g = (B // groups) * (1 if pixel_major else out_shape[1] * out_shape[2])
+                if slots > 0 and (groups == 1 or (B % groups == 0 and rows_g % tile_rows == 0
+                                                  and (not pixel_major or B % tile_rows == 0))):
+                    part = torch.empty(2 * out_shape[3] * slots, dtype=torch.float32, device=cur.device)
+                    bn_part = (part, slots)
+                    bn_fwd = (part, groups, early)
+        ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope, mask=folded, bn_fwd=bn_fwd)
         if _scatter_fwd(st, Cp) and folded is None:    # (measured 12 us faster than tconv1_fwd on the MNIST tail, too)
             m = st.mod
             R, S = m.kernel_size
@@ -497,10 +516,21 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             break
         pact, pslope = (prev.act, prev.slope) if prev is not None else (ACT_NONE, 0.0)
         gt = torch.empty(sv.in_shape, dtype=torch.float32, device=gy.device)
+        bn_red = None
         if sv.bn is None:
             ep = ops.epilogue(mask=sv.mask, dact_y=sv.x_in if pact != ACT_NONE else None, dact=pact, dslope=pslope)
         else:
-            ep = ops.epilogue()
+            # BatchNorm backward needs sum(g~ * xhat) and sum(g~) of the gradient this GEMM produces: its epilogue
+            # accumulates them per M-tile while the values are in registers
+            mask_in = sv.mask if sv.pattern == ["drop", "bn"] else None
+            mask_pre = sv.mask if sv.pattern == ["bn", "drop"] else None
+            slots = ops.conv_mtiles(g, 0 if st.kind == "convT" else 1)[0]
+            if slots > 0 and st.kind in ("conv", "convT") and not _is_tconv1(st, Cp):
+                part = torch.empty(2 * Cp * slots, dtype=torch.float32, device=gy.device)
+                bn_red = (part, slots)
+                ep = ops.epilogue(bn_bwd=(part, sv.x_in, sv.bn_stats[0], sv.bn_stats[1], mask_in, mask_pre))
+            else:
+                ep = ops.epilogue()
         if _is_tconv1(st, Cp) and sv.bn is None and sv.mask is None:
             ops.tconv1_dgrad(g_pre, 1, plan.packed(st, "fwd", Cp), sv.x_in if pact != ACT_NONE else None, pact, pslope,
                              gt, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1], m.padding[0])
@@ -510,15 +540,18 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)
         if sv.bn is not None:
             bn = sv.bn
-            mask_in = sv.mask if sv.pattern == ["drop", "bn"] else None
-            mask_pre = sv.mask if sv.pattern == ["bn", "drop"] else None
             use_batch = sv.training or bn.running_mean is None
             slope = pslope if pact == ACT_LEAKY else -1.0
             want = (i > 0) or need_gx
-            dgam, dbet, gprev = ops.bn_bwd(sv.x_in, gt, mask_in, mask_pre, sv.bn_stats, bn.weight.detach(), B, H * W,
-                                           Cp, use_batch, slope, want_gx=want,
-                                           out_dgamma=grad_dst.get(id(bn.weight)) if need_params else None,
-                                           out_dbeta=grad_dst.get(id(bn.bias)) if need_params else None)
+            out_dg = grad_dst.get(id(bn.weight)) if need_params else None
+            out_db = grad_dst.get(id(bn.bias)) if need_params else None
+            if bn_red is not None:
+                dgam, dbet, gprev = ops.bn_bwd_from_partials(bn_red[0], bn_red[1], sv.x_in, gt, mask_in, mask_pre,
+                                                             sv.bn_stats, bn.weight.detach(), B, H * W, Cp, use_batch,
+                                                             slope, want_gx=want, out_dgamma=out_dg, out_dbeta=out_db)
+            else:
+                dgam, dbet, gprev = ops.bn_bwd(sv.x_in, gt, mask_in, mask_pre, sv.bn_stats, bn.weight.detach(), B, H * W,
+                                               Cp, use_batch, slope, want_gx=want, out_dgamma=out_dg, out_dbeta=out_db)
             if need_params:
                 grads[id(bn.weight)] = dgam
                 grads[id(bn.bias)] = dbet

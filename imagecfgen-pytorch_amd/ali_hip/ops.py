@@ -51,7 +51,11 @@ def geom(B, H, W, C, P, Q, K, R, S, stride, pad) -> AliConvGeom:
     return AliConvGeom(B, H, W, C, P, Q, K, R, S, stride, pad)
 
 
-def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=ACT_NONE, dslope=0.0) -> AliEpilogue:
+def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=ACT_NONE, dslope=0.0,
+             bn_fwd=None, bn_bwd=None) -> AliEpilogue:
+    """``bn_fwd`` = (part, groups, stat_mask or None): also leave the per-tile (sum, sum of squares) of the output;
+    ``bn_bwd`` = (part, x, mean, invstd, mask_in or None, mask_pre or None): per-tile (sum g~*xhat, sum g~) of a data
+    gradient (include/ali_hip.h, AliEpilogue)."""
     ep = AliEpilogue()
     ep.bias = _opt(bias, "bias")
     ep.act, ep.slope = act, slope
@@ -59,7 +63,33 @@ def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=AC
     ep.mask_ld = mask.shape[1] if mask is not None else 0
     ep.dact_y = _opt(dact_y, "dact_y")
     ep.dact, ep.dslope = dact, dslope
+    if bn_fwd is not None:
+        part, groups, smask = bn_fwd
+        ep.bn_part, ep.bn_mode, ep.bn_groups = _chk(part, "bn_part"), 1, groups
+        ep.bn_stat_mask = _opt(smask, "bn_stat_mask")
+        ep.bn_mask_ld = smask.shape[1] if smask is not None else 0
+    elif bn_bwd is not None:
+        part, x, mean, invstd, m_in, m_pre = bn_bwd
+        ep.bn_part, ep.bn_mode, ep.bn_groups = _chk(part, "bn_part"), 2, 1
+        ep.bn_x, ep.bn_mean, ep.bn_invstd = _chk(x, "bn_x"), c_void_p(mean.data_ptr()), c_void_p(invstd.data_ptr())
+        ep.bn_mask_in, ep.bn_mask_pre = _opt(m_in, "bn_mask_in"), _opt(m_pre, "bn_mask_pre")
+        m = m_in if m_in is not None else m_pre
+        ep.bn_mask_ld = m.shape[1] if m is not None else 0
     return ep
+
+
+_MTILES = {}
+
+
+def conv_mtiles(g: AliConvGeom, which: int):
+    """(M-tiles, tile rows, rows ordered (pixel, image)?) of the launch ali_conv_fwd (0) / ali_conv_bwd_data (1) makes."""
+    key = (which,) + tuple(getattr(g, n) for n, _ in AliConvGeom._fields_)
+    hit = _MTILES.get(key)
+    if hit is None:
+        rows, pm = ctypes.c_int32(0), ctypes.c_int32(0)
+        n = _lib.load().ali_conv_mtiles(byref(g), which, byref(rows), byref(pm))
+        hit = _MTILES[key] = (n, rows.value, bool(pm.value))
+    return hit
 
 
 class KernelProfile:
@@ -329,6 +359,34 @@ def bn_stats(x, mask, B, rows_per_img, C, gamma, beta, running_mean, running_var
                                 c_void_p(st[0, 2].data_ptr()), c_void_p(st[0, 3].data_ptr()), groups, 4 * C,
                                 c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_bn_stats")
     return st[0] if groups == 1 else st
+
+
+def bn_stats_from_partials(part, slots, groups, C, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """bn_stats (training mode) from the per-tile partial sums a convolution epilogue left in ``part``."""
+    lib = _lib.load()
+    st = torch.empty(groups, 4, C, dtype=torch.float32, device=part.device)
+    _lib.check(lib.ali_bn_stats_from_partials(_chk(part, "part"), slots, groups, C, count, _opt(gamma), _opt(beta),
+                                              _opt(running_mean), _opt(running_var), momentum, eps,
+                                              c_void_p(st[0, 0].data_ptr()), c_void_p(st[0, 1].data_ptr()),
+                                              c_void_p(st[0, 2].data_ptr()), c_void_p(st[0, 3].data_ptr()), 4 * C,
+                                              _stream()), "ali_bn_stats_from_partials")
+    return st[0] if groups == 1 else st
+
+
+def bn_bwd_from_partials(part, slots, x, g, mask_in, mask_pre, st, gamma, B, rows_per_img, C, batch_stats, slope,
+                         want_gx=True, out_dgamma=None, out_dbeta=None):
+    """bn_bwd from the per-tile partial sums the data-gradient GEMM's epilogue left in ``part``."""
+    lib = _lib.load()
+    if out_dgamma is None or out_dbeta is None:
+        dg = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        out_dgamma, out_dbeta = dg[0], dg[1]
+    gx = torch.empty_like(x) if want_gx else None
+    _lib.check(lib.ali_bn_bwd_from_partials(_chk(part, "part"), slots, _chk(x, "x"), _chk(g, "g"), _opt(mask_in),
+                                            _opt(mask_pre), c_void_p(st[0].data_ptr()), c_void_p(st[1].data_ptr()),
+                                            _opt(gamma), B, rows_per_img, C, int(batch_stats), float(slope),
+                                            _chk(out_dgamma, "dgamma"), _chk(out_dbeta, "dbeta"), _opt(gx), _stream()),
+               "ali_bn_bwd_from_partials")
+    return out_dgamma, out_dbeta, gx
 
 
 def bn_apply(x, st, mask_in, mask_post, B, rows_per_img, C, out=None, groups=1):

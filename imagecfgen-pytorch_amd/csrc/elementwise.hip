@@ -190,7 +190,10 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, const float
     part[((long long)blockIdx.x * 2 + 1) * C + tc] = red2[t];
   }
 }
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblk, int C, long long count,
+// partial (b, s, c) of group gi lives at part[gi*lay.g + b*lay.b + s*lay.s + c*lay.c]: [nblk][2][C] blocks per group for
+// the reduction kernels above, [2][C][slots] (slots of a group contiguous) for partials left by a convolution epilogue
+struct PartLayout { long long g, b, s, c; };
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, PartLayout lay, int nblk, int C, long long count,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                       float momentum, float eps, int training, float* __restrict__ mean_out,
@@ -198,13 +201,13 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblk, 
                                       int groups, long long stat_stride) {
   const int c = blockIdx.x;   // one wave per channel; the groups (batched passes) update the running stats in order
   for (int gi = 0; gi < groups; ++gi) {
-    const float* pg = part + (long long)gi * nblk * 2 * C;
+    const float* pg = part + (long long)gi * lay.g + (long long)c * lay.c;
     float mean, var;
     if (training) {
       double s1 = 0.0, s2 = 0.0;
       for (int b = threadIdx.x; b < nblk; b += 64) {
-        s1 += (double)pg[((long long)b * 2 + 0) * C + c];
-        s2 += (double)pg[((long long)b * 2 + 1) * C + c];
+        s1 += (double)pg[(long long)b * lay.b];
+        s2 += (double)pg[(long long)b * lay.b + lay.s];
       }
       s1 = wave_sum(s1);
       s2 = wave_sum(s2);
@@ -288,13 +291,14 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
     part[((long long)blockIdx.x * 2 + 1) * C + tc] = red2[t];
   }
 }
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, PartLayout lay, int nblk, int C,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x;   // one wave per channel
   double s1 = 0.0, s2 = 0.0;
+  const float* pg = part + (long long)c * lay.c;
   for (int b = threadIdx.x; b < nblk; b += 64) {
-    s1 += (double)part[((long long)b * 2 + 0) * C + c];
-    s2 += (double)part[((long long)b * 2 + 1) * C + c];
+    s1 += (double)pg[(long long)b * lay.b];
+    s2 += (double)pg[(long long)b * lay.b + lay.s];
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
@@ -831,10 +835,28 @@ extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_
     for (int gi = 0; gi < groups; ++gi)
       hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x + (size_t)gi * rows * C,
                          mask ? mask + (size_t)gi * Bg * C : nullptr, rows, rows_per_img, C, part + (size_t)gi * nb * 2 * C);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, rows, gamma, beta,
+  const PartLayout lay = {(long long)nb * 2 * C, 2LL * C, (long long)C, 1LL};
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, nb, C, rows, gamma, beta,
                      running_mean, running_var, momentum, eps, training, mean, invstd, sc, sh, groups,
                      (long long)stat_stride);
   return check_launch("bn_stats");
+}
+
+extern "C" int ali_bn_stats_from_partials(const float* part, int32_t slots, int32_t groups, int32_t C, int64_t count,
+                                          const float* gamma, const float* beta, float* running_mean,
+                                          float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                          float* sc, float* sh, int64_t stat_stride, ali_stream_t stream) {
+  if (!part || slots <= 0 || groups < 1 || slots % groups != 0 || C <= 0 || count <= 0 || !mean || !invstd || !sc || !sh ||
+      (groups > 1 && stat_stride < C)) {
+    set_error("ali_bn_stats_from_partials: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  const int per = slots / groups;
+  const PartLayout lay = {(long long)per, 1LL, (long long)C * slots, (long long)slots};
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, per, C, (long long)count, gamma,
+                     beta, running_mean, running_var, momentum, eps, 1, mean, invstd, sc, sh, groups,
+                     (long long)stat_stride);
+  return check_launch("bn_stats_from_partials");
 }
 
 extern "C" int ali_bn_apply(const float* x, const float* sc, const float* sh, const float* mask_in,
@@ -856,6 +878,20 @@ extern "C" int ali_bn_apply(const float* x, const float* sc, const float* sh, co
                          sc + gi * stat_stride, sh + gi * stat_stride, mask_in ? mask_in + (size_t)gi * Bg * C : nullptr,
                          mask_post ? mask_post + (size_t)gi * Bg * C : nullptr, out + (size_t)gi * n, n, rows_per_img, C);
   return check_launch("bn_apply_kernel");
+}
+
+static void launch_bn_bwd_apply(const float* x, const float* g, const float* mask_in, const float* mask_pre,
+                                const float* mean, const float* invstd, const float* gamma, const float* dgamma,
+                                const float* dbeta, long long rows, int rows_per_img, int C, int batch_stats,
+                                float lrelu_slope, float* gx, bool vec, hipStream_t stream) {
+  const long long n = rows * C;
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(ew_grid(n / 4)), dim3(kEwBlock), 0, stream, x, g, mask_in, mask_pre,
+                       mean, invstd, gamma, dgamma, dbeta, (unsigned)rows, (unsigned)rows_per_img, (unsigned)C,
+                       1.f / (float)rows, batch_stats, lrelu_slope, gx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, stream, x, g, mask_in, mask_pre, mean,
+                       invstd, gamma, dgamma, dbeta, n, rows_per_img, C, 1.f / (float)rows, batch_stats, lrelu_slope, gx);
 }
 
 extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, const float* mask_pre,
@@ -881,19 +917,31 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
   else
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean, invstd,
                        rows, rows_per_img, C, part);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, nb, C, dgamma, dbeta);
-  if (gx) {
-    const long long n = rows * C;
-    if (vec)
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(ew_grid(n / 4)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in,
-                         mask_pre, mean, invstd, gamma, dgamma, dbeta, (unsigned)rows, (unsigned)rows_per_img,
-                         (unsigned)C, 1.f / (float)rows, batch_stats, lrelu_slope, gx);
-    else
-      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n)), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre,
-                         mean, invstd, gamma, dgamma, dbeta, n, rows_per_img, C, 1.f / (float)rows, batch_stats,
-                         lrelu_slope, gx);
-  }
+  const PartLayout lay = {0LL, 2LL * C, (long long)C, 1LL};
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, nb, C, dgamma, dbeta);
+  if (gx) launch_bn_bwd_apply(x, g, mask_in, mask_pre, mean, invstd, gamma, dgamma, dbeta, rows, rows_per_img, C,
+                              batch_stats, lrelu_slope, gx, vec, ST(stream));
   return check_launch("bn_bwd");
+}
+
+extern "C" int ali_bn_bwd_from_partials(const float* part, int32_t slots, const float* x, const float* g,
+                                        const float* mask_in, const float* mask_pre, const float* mean,
+                                        const float* invstd, const float* gamma, int32_t B, int32_t rows_per_img,
+                                        int32_t C, int32_t batch_stats, float lrelu_slope, float* dgamma, float* dbeta,
+                                        float* gx, ali_stream_t stream) {
+  if (!part || slots <= 0 || !x || !g || !mean || !invstd || !dgamma || !dbeta || B <= 0 || rows_per_img <= 0 || C <= 0) {
+    set_error("ali_bn_bwd_from_partials: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  const long long rows = (long long)B * rows_per_img;
+  const bool vec = vec_ok(rows, C) && aligned16(x) && aligned16(g) && (!gx || aligned16(gx)) &&
+                   (!mask_in || aligned16(mask_in)) && (!mask_pre || aligned16(mask_pre)) && aligned16(mean) &&
+                   aligned16(invstd);
+  const PartLayout lay = {0LL, 1LL, (long long)C * slots, (long long)slots};
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, slots, C, dgamma, dbeta);
+  if (gx) launch_bn_bwd_apply(x, g, mask_in, mask_pre, mean, invstd, gamma, dgamma, dbeta, rows, rows_per_img, C,
+                              batch_stats, lrelu_slope, gx, vec, ST(stream));
+  return check_launch("bn_bwd_from_partials");
 }
 
 extern "C" int ali_plane_table_grad(const float* g, int32_t g_ld, int32_t g_ch, const float* x, int32_t x_ld, int32_t x_ch,

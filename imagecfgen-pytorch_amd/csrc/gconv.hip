@@ -482,8 +482,15 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   // epilogue: acc(row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31).  Row offsets are fetched from LDS in one
   // batch, the optional mask / act' operands in one batch of global loads (no branch, no wait per element).
   const AliEpilogue& ep = d.ep;
-  auto run_epilogue = [&](auto has_mask_t, auto has_dact_t, const bool partial, float* outp) {
+  // BNM (fused BatchNorm reductions, see AliEpilogue): 0 none; 1 column sums (v~, v~^2) of the stored value; 2 column
+  // sums (g~ * xhat, g~) of a data gradient.  Accumulated per lane over its rows, combined across the half-waves,
+  // then across the tile's row-waves through LDS in a fixed order: deterministic, no atomics.
+  auto run_epilogue = [&](auto has_mask_t, auto has_dact_t, auto bn_t, const bool partial, float* outp) {
     constexpr bool HAS_MASK = decltype(has_mask_t)::value, HAS_DACT = decltype(has_dact_t)::value;
+    constexpr int BNM = decltype(bn_t)::value;
+    float bs0[TN], bs1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bs0[j] = bs1[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
           const int r = h * 8 + q;
           const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           roff[q] = s_rowoff[row];
-          if (HAS_MASK) rimg[q] = s_rowimg[row];
+          if (HAS_MASK || BNM != 0) rimg[q] = s_rowimg[row];
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -502,7 +509,8 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
           const bool nok = n < d.Cout;
           const int nc = nok ? n : 0;
           const float bias = partial ? 0.f : bias_pre[j];
-          float mk[8], dy[8];
+          float mk[8], dy[8], bx[8], bm1[8], bm2[8];
+          float bmu = 0.f, bis = 0.f;
           if (HAS_MASK) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) mk[q] = ep.mask[(long long)rimg[q] * ep.mask_ld + nc];
@@ -510,6 +518,21 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
           if (HAS_DACT) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) dy[q] = ep.dact_y[(roff[q] < 0 ? 0 : roff[q]) + nc];
+          }
+          if (BNM == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              bm1[q] = ep.bn_stat_mask ? ep.bn_stat_mask[(long long)rimg[q] * ep.bn_mask_ld + nc] : 1.f;
+          }
+          if (BNM == 2) {
+            bmu = ep.bn_mean[nc];
+            bis = ep.bn_invstd[nc];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              bx[q] = ep.bn_x[(roff[q] < 0 ? 0 : roff[q]) + nc];
+              bm1[q] = ep.bn_mask_in ? ep.bn_mask_in[(long long)rimg[q] * ep.bn_mask_ld + nc] : 1.f;
+              bm2[q] = ep.bn_mask_pre ? ep.bn_mask_pre[(long long)rimg[q] * ep.bn_mask_ld + nc] : 1.f;
+            }
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -522,12 +545,59 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
             if (nok && roff[q] >= 0) {
               if (partial) __hip_atomic_store(outp + roff[q] + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               else outp[roff[q] + n] = v;
+              if (BNM == 1) {
+                const float vs = v * bm1[q];
+                bs0[j] += vs;
+                bs1[j] += vs * vs;
+              }
+              if (BNM == 2) {
+                const float gs = v * bm2[q];
+                bs0[j] += gs * ((bx[q] * bm1[q] - bmu) * bis);
+                bs1[j] += gs;
+              }
             }
           }
         }
       }
     }
+    if (BNM != 0) {
+      // the k-loop is over for every wave of the block (it ends in a barrier; the split-K winner passed two more):
+      // the operand tiles in LDS are dead and serve as scratch [2][WAVES_M][BN]
+      float* red = &As[0][0];
+      static_assert(2 * WAVES_M * BN <= BM * LDK, "reduction scratch fits the A tile");
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bs0[j] += __shfl_xor(bs0[j], 32, 64);
+        bs1[j] += __shfl_xor(bs1[j], 32, 64);
+        if (lane < 32) {
+          red[(0 * WAVES_M + wm) * BN + wn * WN + j * 32 + lane] = bs0[j];
+          red[(1 * WAVES_M + wm) * BN + wn * WN + j * 32 + lane] = bs1[j];
+        }
+      }
+      __syncthreads();
+      if (t < BN && n0 + t < d.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          a += red[(0 * WAVES_M + w) * BN + t];
+          b += red[(1 * WAVES_M + w) * BN + t];
+        }
+        int slot = blockIdx.x;
+        const int nslots = gridDim.x;
+        if (ep.bn_groups > 1 && P.pixmajor) {   // tiles of one pixel position: images [0,B) in order, passes back to back
+          const int tpp = d.B / BM, tpg = tpp / ep.bn_groups;
+          const int pix = (int)blockIdx.x / tpp, tin = (int)blockIdx.x - pix * tpp;
+          const int grp = tin / tpg;
+          slot = grp * (nslots / ep.bn_groups) + pix * tpg + (tin - grp * tpg);
+        }
+        ep.bn_part[((long long)0 * d.Cout + n0 + t) * nslots + slot] = a;
+        ep.bn_part[((long long)1 * d.Cout + n0 + t) * nslots + slot] = b;
+      }
+    }
   };
+  using BN0 = std::integral_constant<int, 0>;
+  using BN1 = std::integral_constant<int, 1>;
+  using BN2 = std::integral_constant<int, 2>;
   using T_ = std::true_type;
   using F_ = std::false_type;
   if (d.splitk > 1) {
@@ -549,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     //     launch.  The counter is reset by the winner alone, after all arrivals: the next launch (stream order)
     //     finds it at zero.
     // Nothing else is shared between the blocks of a tile, so no cache-wide fence is required.
-    run_epilogue(F_{}, F_{}, true, d.ws + (long long)blockIdx.z * d.out_elems);
+    run_epilogue(F_{}, F_{}, BN0{}, true, d.ws + (long long)blockIdx.z * d.out_elems);
     __shared__ int s_last;
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -612,10 +682,15 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     }
   }
   const bool hm = ep.mask != nullptr, hd = ep.dact_y != nullptr;
-  if (hm && hd) run_epilogue(T_{}, T_{}, false, d.out);
-  else if (hm) run_epilogue(T_{}, F_{}, false, d.out);
-  else if (hd) run_epilogue(F_{}, T_{}, false, d.out);
-  else run_epilogue(F_{}, F_{}, false, d.out);
+  if (ep.bn_part != nullptr) {   // host: mode 1 never comes with dact_y, mode 2 with neither mask nor dact_y
+    if (ep.bn_mode == 2) run_epilogue(F_{}, F_{}, BN2{}, false, d.out);
+    else if (hm) run_epilogue(T_{}, F_{}, BN1{}, false, d.out);
+    else run_epilogue(F_{}, F_{}, BN1{}, false, d.out);
+  }
+  else if (hm && hd) run_epilogue(T_{}, T_{}, BN0{}, false, d.out);
+  else if (hm) run_epilogue(T_{}, F_{}, BN0{}, false, d.out);
+  else if (hd) run_epilogue(F_{}, T_{}, BN0{}, false, d.out);
+  else run_epilogue(F_{}, F_{}, BN0{}, false, d.out);
 }
 
 struct TileCfg { int bm, bn; };
@@ -635,18 +710,16 @@ static TileCfg pick_tile(long long M, int N) {
   return best;
 }
 
-static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec, bool dense_k) {
+// tile shape, row order and M-tile count of a launch (everything the grid's x extent depends on)
+static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps) {
   long long Mtot = 0;
-  int max_taps = 0;
+  max_taps = 0;
   for (int i = 0; i < d.nphase; ++i) {
     Mtot += d.ph[i].M;
     if (d.ph[i].nr * d.ph[i].ns > max_taps) max_taps = d.ph[i].nr * d.ph[i].ns;
-    if (d.ph[i].M >= (1 << 24)) { set_error("gconv: more than 2^24 rows in one phase"); return ALI_ERR_BAD_ARG; }
+    if (d.ph[i].M >= (1 << 24)) { set_error("gconv: more than 2^24 rows in one phase"); return -1; }
   }
-  const int max_nkt = (max_taps * d.Cin + BK - 1) / BK;
-  const bool uni = vec && (d.Cin % BK) == 0;
-  const bool pow2 = vec && (d.Cin == 4 || d.Cin == 8 || d.Cin == 16) && max_taps <= kMaxTaps;
-  TileCfg tc = pick_tile(Mtot, d.Cout);
+  tc = pick_tile(Mtot, d.Cout);
   if (!vec && tc.bn == 128) tc.bn = 64;
   if (tuning().bm > 0 && tuning().bn > 0) { tc.bm = tuning().bm; tc.bn = tuning().bn; }
   int tiles = 0;
@@ -656,6 +729,28 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     d.ph[i].pixmajor = (d.ph[i].Hq * d.ph[i].Wq <= 1024 && d.B >= 64) ? 1 : 0;
     d.ph[i].tile0 = tiles;
     tiles += (d.ph[i].M + tc.bm - 1) / tc.bm;
+  }
+  return tiles;
+}
+
+static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec, bool dense_k) {
+  TileCfg tc;
+  int max_taps = 0;
+  const int tiles = plan_tiles(d, vec, tc, max_taps);
+  if (tiles < 0) return ALI_ERR_BAD_ARG;
+  const int max_nkt = (max_taps * d.Cin + BK - 1) / BK;
+  const bool uni = vec && (d.Cin % BK) == 0;
+  const bool pow2 = vec && (d.Cin == 4 || d.Cin == 8 || d.Cin == 16) && max_taps <= kMaxTaps;
+  if (d.ep.bn_part) {
+    const AliEpilogue& e = d.ep;
+    bool ok = (e.bn_mode == 1 || e.bn_mode == 2) && !e.dact_y;
+    if (e.bn_mode == 2) ok = ok && !e.mask && e.bn_x && e.bn_mean && e.bn_invstd && e.bn_groups <= 1;
+    if (e.bn_mode == 1 && e.bn_groups > 1) {
+      ok = ok && d.nphase == 1 && d.B % e.bn_groups == 0;
+      const long long rows_g = (long long)(d.B / e.bn_groups) * (d.ph[0].pixmajor ? 1 : d.ph[0].Hq * d.ph[0].Wq);
+      ok = ok && rows_g % tc.bm == 0 && (!d.ph[0].pixmajor || d.B % tc.bm == 0);
+    }
+    if (!ok) { set_error("gconv: bad fused BatchNorm epilogue (see AliEpilogue / ali_conv_mtiles)"); return ALI_ERR_BAD_ARG; }
   }
   const int ntile_n = (d.Cout + tc.bn - 1) / tc.bn;
   d.out_elems = (long long)d.B * d.Hout * d.Wout * d.ldo;
@@ -744,13 +839,7 @@ extern "C" size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which) 
   return kWsReserved + (size_t)64 * g->R * g->S * g->C * g->K * sizeof(float);
 }
 
-extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
-                            void* ws, size_t ws_bytes, ali_stream_t stream) {
-  if (!geom_ok(g) || !x || !w || !y) { set_error("ali_conv_fwd: bad argument"); return ALI_ERR_BAD_ARG; }
-  GDesc d;
-  memset(&d, 0, sizeof(d));
-  d.in = x; d.w = w; d.out = y;
-  fill_epilogue(d, ep);
+static void setup_fwd(const AliConvGeom* g, GDesc& d) {
   d.B = g->B; d.Hin = g->H; d.Win = g->W; d.Cin = g->C;
   d.Hout = g->P; d.Wout = g->Q; d.Cout = g->K; d.ldo = g->K;
   d.ldw = g->R * g->S * g->C;
@@ -762,22 +851,15 @@ extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w
   P.nr = g->R; P.ns = g->S;
   for (int r = 0; r < g->R; ++r) { P.dh[r] = (signed char)(r - g->pad); P.wr[r] = (unsigned char)r; }
   for (int s = 0; s < g->S; ++s) { P.dw[s] = (signed char)(s - g->pad); P.ws[s] = (unsigned char)s; }
-  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->C % 4) == 0, g->pad == 0);
 }
 
-extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w, float* dx,
-                                 const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream) {
-  if (!geom_ok(g) || !dy || !w || !dx) { set_error("ali_conv_bwd_data: bad argument"); return ALI_ERR_BAD_ARG; }
-  GDesc d;
-  memset(&d, 0, sizeof(d));
-  d.in = dy; d.w = w; d.out = dx;
-  fill_epilogue(d, ep);
+static bool setup_bwd_data(const AliConvGeom* g, GDesc& d) {
   d.B = g->B; d.Hin = g->P; d.Win = g->Q; d.Cin = g->K;
   d.Hout = g->H; d.Wout = g->W; d.Cout = g->C; d.ldo = g->C;
   d.ldw = g->R * g->S * g->K;
   d.S = g->S;
   const int st = g->stride;
-  if (st > 2) { set_error("ali_conv_bwd_data: stride %d unsupported", st); return ALI_ERR_BAD_ARG; }
+  if (st > 2) { set_error("ali_conv_bwd_data: stride %d unsupported", st); return false; }
   d.nphase = 0;
   for (int ph = 0; ph < st; ++ph)
     for (int pw = 0; pw < st; ++pw) {
@@ -802,5 +884,43 @@ extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const fl
         ++P.ns;
       }
     }
+  return true;
+}
+
+extern "C" int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t* tile_rows, int32_t* pixel_major) {
+  if (!geom_ok(g) || (which != 0 && which != 1)) return 0;
+  GDesc d;
+  memset(&d, 0, sizeof(d));
+  bool vec;
+  if (which == 0) { setup_fwd(g, d); vec = (g->C % 4) == 0; }
+  else { if (!setup_bwd_data(g, d)) return 0; vec = (g->K % 4) == 0; }
+  TileCfg tc;
+  int max_taps = 0;
+  const int tiles = plan_tiles(d, vec, tc, max_taps);
+  if (tiles < 0) return 0;
+  if (tile_rows) *tile_rows = tc.bm;
+  if (pixel_major) *pixel_major = d.ph[0].pixmajor;
+  return tiles;
+}
+
+extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
+                            void* ws, size_t ws_bytes, ali_stream_t stream) {
+  if (!geom_ok(g) || !x || !w || !y) { set_error("ali_conv_fwd: bad argument"); return ALI_ERR_BAD_ARG; }
+  GDesc d;
+  memset(&d, 0, sizeof(d));
+  d.in = x; d.w = w; d.out = y;
+  fill_epilogue(d, ep);
+  setup_fwd(g, d);
+  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->C % 4) == 0, g->pad == 0);
+}
+
+extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w, float* dx,
+                                 const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream) {
+  if (!geom_ok(g) || !dy || !w || !dx) { set_error("ali_conv_bwd_data: bad argument"); return ALI_ERR_BAD_ARG; }
+  GDesc d;
+  memset(&d, 0, sizeof(d));
+  d.in = dy; d.w = w; d.out = dx;
+  fill_epilogue(d, ep);
+  if (!setup_bwd_data(g, d)) return ALI_ERR_BAD_ARG;
   return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->K % 4) == 0, false);
 }

@@ -56,7 +56,20 @@ typedef struct {
 /* Optional fused epilogue, applied in this order to v = acc:
  *   v += bias[n]; v = act(v); v *= mask[img*mask_ld + n]; v *= act'(dact_y)
  * dact_y has the layout of the output; act' is evaluated on the *activated*
- * value saved in forward (leaky: y>0 ? 1 : slope, tanh: 1-y*y).            */
+ * value saved in forward (leaky: y>0 ? 1 : slope, tanh: 1-y*y).
+ *
+ * Fused BatchNorm2d reductions (mnist.py:111,114,118,122; bn_mode != 0): the launch also leaves, per M-tile of its
+ * grid ("slot"; ali_conv_mtiles tells how many), the column sums over the tile's rows that nn.BatchNorm2d needs, so no
+ * separate pass over the tensor is made:
+ *   bn_mode 1 (the conv in front of a BatchNorm, forward): s0 = sum v~, s1 = sum v~^2 with v~ = v * bn_stat_mask[img,n]
+ *             (a Dropout2d between the conv and the BatchNorm; NULL: v~ = v, the stored value);
+ *   bn_mode 2 (the data-gradient GEMM behind a BatchNorm, backward): s0 = sum g~ * xhat, s1 = sum g~ with
+ *             g~ = v * bn_mask_pre[img,n], xhat = (bn_x * bn_mask_in[img,n] - bn_mean[n]) * bn_invstd[n]; bn_x has the
+ *             layout of the output.
+ * bn_part[(s*N + n) * slots + slot(tile)], slots = number of M-tiles.  bn_groups > 1 (mode 1): the batch is that many
+ * passes back to back (B/groups images each, B/groups a multiple of the tile height: ali_conv_mtiles reports it);
+ * the slots of pass g are the contiguous range [g*slots/groups, (g+1)*slots/groups).  Consumed by
+ * ali_bn_stats_from_partials / ali_bn_bwd_from_partials. */
 typedef struct {
   const float* bias;   /* [N] or NULL */
   int32_t act;         /* AliAct */
@@ -66,6 +79,15 @@ typedef struct {
   const float* dact_y; /* or NULL */
   int32_t dact;        /* AliAct of the producer of dact_y */
   float dslope;
+  float* bn_part;      /* or NULL */
+  int32_t bn_mode, bn_groups;
+  const float* bn_stat_mask;   /* mode 1, or NULL; row stride bn_mask_ld */
+  int32_t bn_mask_ld;
+  const float* bn_x;           /* mode 2 */
+  const float* bn_mean;
+  const float* bn_invstd;
+  const float* bn_mask_in;     /* mode 2, or NULL; row stride bn_mask_ld */
+  const float* bn_mask_pre;    /* mode 2, or NULL; row stride bn_mask_ld */
 } AliEpilogue;
 
 /* ---- implicit-GEMM convolutions (fp32 MFMA v_mfma_f32_32x32x2_f32) -------
@@ -82,6 +104,11 @@ typedef struct {
  *                      with gc = channel of x (logical count Cg_log), dc =
  *                      channel of dy (logical count Cd_log), t = r*S+s.     */
 size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which /*0 fwd,1 bwd_data,2 bwd_weight*/);
+/* Number of M-tiles (= bn_part slots) ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) will launch for this
+ * geometry, and the tile height in *tile_rows; 0 for a bad geometry.  Rows are ordered (pixel, image) when
+ * *pixel_major != 0 (then bn_groups needs B/groups % tile_rows == 0), (image, pixel) otherwise (then it needs
+ * B/groups * P*Q % tile_rows == 0). */
+int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t* tile_rows, int32_t* pixel_major);
 int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w_kxc, float* y,
                  const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
 int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w_cxk, float* dx,
@@ -177,6 +204,18 @@ int ali_bn_bwd(const float* x, const float* g, const float* mask_in, const float
                const float* mean, const float* invstd, const float* gamma,
                int32_t B, int32_t rows_per_img, int32_t C, int32_t batch_stats, float lrelu_slope,
                float* dgamma, float* dbeta, float* gx, void* ws, size_t ws_bytes, ali_stream_t stream);
+
+/* The same two ops fed by the per-tile partial sums a convolution launch left in `part` (AliEpilogue.bn_part, slots =
+ * M-tiles of that launch): no reduction pass over the tensor.  stats: training mode only, `count` = rows per pass
+ * (B/groups * H*W).  bwd: dgamma / dbeta from the partials, then the elementwise gx pass of ali_bn_bwd. */
+int ali_bn_stats_from_partials(const float* part, int32_t slots, int32_t groups, int32_t C, int64_t count,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, float* mean, float* invstd, float* sc, float* sh,
+                               int64_t stat_stride, ali_stream_t stream);
+int ali_bn_bwd_from_partials(const float* part, int32_t slots, const float* x, const float* g, const float* mask_in,
+                             const float* mask_pre, const float* mean, const float* invstd, const float* gamma,
+                             int32_t B, int32_t rows_per_img, int32_t C, int32_t batch_stats, float lrelu_slope,
+                             float* dgamma, float* dbeta, float* gx, ali_stream_t stream);
 
 /* nn.BCEWithLogitsLoss (mean) against a constant target, forward + gradient,
  * and the diagnostic sigmoid().mean() (mnist.py:181,228-248).

@@ -61,9 +61,11 @@ def test_bs512_stepper_vs_reference_trajectory(golden_dir):
                 # running statistics after 12 updates, the last 8 with weights that already took sign-like Adam
                 # steps (an element whose gradient is at rounding level may step the other way): measured 1.0e-3
                 close(v.float(), so[k].float(), 3e-3, f"{nm}.{k}")
-            else:   # an Adam update is sign-like: |delta| <= ~lr per step whatever the gradient's size
+            else:   # an Adam update is sign-like: |delta| <= ~lr per step whatever the gradient's size, so two runs
+                # differ by at most 2*lr per optimiser step where a rounding-level gradient changed sign
+                steps = 4 if nm == "D" else 2             # two iterations: E+G step once, D twice per iteration
                 diff = (v.cpu().double() - so[k].double()).abs()
-                assert diff.max().item() <= 2 * 2.2e-4, (nm, k, diff.max().item())
+                assert diff.max().item() <= steps * 2.2e-4, (nm, k, diff.max().item())
                 if v.numel() >= 10000:
                     assert diff.mean().item() <= 0.1 * 1e-4, (nm, k, diff.mean().item())
 

@@ -450,3 +450,83 @@ def test_full_size_adjoint_identities(kind, B, C, H, K, R, stride, pad):
     c = (dw.double() * w.double()).sum().item()
     scale = (dy.double().norm() * y.double().norm()).item()
     assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+
+
+FUSED_BN_CASES = [
+    # B, C, H, K, R, stride, groups, drop      (MNIST D.dx: mnist.py:108-123) + ragged / split-K / 128-row tiles
+    (256, 8, 28, 32, 5, 1, 2, True), (128, 32, 24, 64, 4, 2, 2, False), (128, 64, 11, 128, 4, 1, 1, False),
+    (256, 128, 8, 256, 4, 2, 2, False), (70, 32, 9, 64, 4, 2, 1, True), (512, 128, 8, 256, 4, 2, 1, False),
+]
+
+
+@pytest.mark.parametrize("B,C,H,K,R,stride,groups,drop", FUSED_BN_CASES)
+def test_batchnorm_reductions_fused_into_the_gemm_epilogues(B, C, H, K, R, stride, groups, drop):
+    """nn.BatchNorm2d's batch statistics accumulated by the producing Conv2d's epilogue (optionally through a Dropout2d
+    mask, per pass of a batched launch) and its backward reductions accumulated by the data-gradient GEMM's epilogue
+    (AliEpilogue.bn_mode 1 / 2 + ali_bn_*_from_partials) vs torch's BatchNorm2d on the CPU (mnist.py:108-123)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + 7 * K)
+    x = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    mask = (torch.rand(B, K, generator=g) > 0.3).float() / 0.7 if drop else None
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    P = (H - R) // stride + 1
+    Bg = B // groups
+    # ---- reference: conv -> lrelu -> [drop] -> bn (batch stats per pass), then a second conv's data gradient arrives
+    wr = w.clone()
+    y = F.leaky_relu(F.conv2d(x, wr, b, stride=stride), 0.1)
+    ym = y * mask.reshape(B, K, 1, 1) if drop else y
+    bn = torch.nn.BatchNorm2d(K)
+    with torch.no_grad():
+        bn.weight.copy_(gamma), bn.bias.copy_(beta)
+    bn.train()
+    outs = [bn(ym[i * Bg:(i + 1) * Bg]) for i in range(groups)]
+    # ---- HIP: conv with fused statistics
+    xh = nhwc(x).cuda()
+    geom = ops.geom(B, H, H, C, P, P, K, R, R, stride, 0)
+    slots, tile_rows, pm = ops.conv_mtiles(geom, 0)
+    part = torch.full((2 * K * slots,), float("nan"), device="cuda")
+    yh = torch.empty(B, P, P, K, device="cuda")
+    maskc = mask.cuda() if drop else None
+    ops.conv_fwd(geom, xh, pack_conv_fwd(ops, w, C), yh,
+                 ops.epilogue(bias=b.cuda(), act=ops.ACT_LEAKY, slope=0.1, bn_fwd=(part, groups, maskc)))
+    close(nchw(yh), y, what="conv out (stored unmasked)")
+    rm, rv = torch.zeros(K, device="cuda"), torch.ones(K, device="cuda")
+    st = ops.bn_stats_from_partials(part, slots, groups, K, Bg * P * P, gamma.cuda(), beta.cuda(), rm, rv, 0.1, 1e-5)
+    st = st.reshape(groups, 4, K)
+    for gi in range(groups):
+        ref = ym[gi * Bg:(gi + 1) * Bg]
+        close(st[gi, 0], ref.mean(dim=(0, 2, 3)), 1e-5, f"mean pass {gi}")
+        close(1 / st[gi, 1] ** 2 - 1e-5, ref.var(dim=(0, 2, 3), unbiased=False), 1e-4, f"var pass {gi}")
+    close(rm, bn.running_mean, 1e-5, "running_mean")
+    close(rv, bn.running_var, 1e-5, "running_var")
+    t = ops.bn_apply(yh, st[0] if groups == 1 else st, maskc, None, B, P * P, K, groups=groups)
+    close(nchw(t), torch.cat(outs), what="bn out")
+    # ---- backward of pass 0 through bn (+drop) with the reductions fused into a data-gradient GEMM's epilogue:
+    # the consumer is a second conv K -> K2 (3x3 if the map allows), whose dgrad produces g = dL/dt
+    R2 = 3 if P >= 3 else 1
+    K2 = 64
+    w2 = torch.randn(K2, K, R2, R2, generator=g) / (K * R2 * R2) ** 0.5
+    P2 = P - R2 + 1
+    gy2 = torch.randn(Bg, K2, P2, P2, generator=g)
+    y0 = y[:Bg].clone().requires_grad_(True)
+    bn2 = torch.nn.BatchNorm2d(K)
+    with torch.no_grad():
+        bn2.weight.copy_(gamma), bn2.bias.copy_(beta)
+    bn2.train()
+    t0 = bn2(y0 * mask[:Bg].reshape(Bg, K, 1, 1) if drop else y0)
+    F.conv2d(t0, w2).backward(gy2)
+    geom2 = ops.geom(Bg, P, P, K, P2, P2, K2, R2, R2, 1, 0)
+    slots2 = ops.conv_mtiles(geom2, 1)[0]
+    part2 = torch.full((2 * K * slots2,), float("nan"), device="cuda")
+    gt = torch.empty(Bg, P, P, K, device="cuda")
+    x_in = yh[:Bg].contiguous()
+    m0 = maskc[:Bg].contiguous() if drop else None
+    ops.conv_bwd_data(geom2, nhwc(gy2).cuda(), pack_conv_dgrad(ops, w2, K), gt,
+                      ops.epilogue(bn_bwd=(part2, x_in, st[0, 0], st[0, 1], m0, None)))
+    dgam, dbet, gprev = ops.bn_bwd_from_partials(part2, slots2, x_in, gt, m0, None, st[0], gamma.cuda(), Bg, P * P, K,
+                                                 True, -1.0)
+    close(dgam, bn2.weight.grad, what="dgamma")
+    close(dbet, bn2.bias.grad, what="dbeta")
+    close(nchw(gprev), y0.grad, what="gx")

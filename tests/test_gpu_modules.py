@@ -333,11 +333,13 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
     bce = nn.BCEWithLogitsLoss()
     lr = 1e-4
 
-    def check_update(mods_o, mods_p, before, g_ref, what):
+    def check_update(mods_o, mods_p, before, g_ref, what, ties=0):
         """Adam's first steps are sign-like: +-lr whatever the gradient's size.  An element whose gradient is at the
         gradients' noise level (|g| of the order of the GPU-vs-CPU difference: a summation-order effect, or the
         one-sample contribution of a LeakyReLU input at fp32 noise level -- at bs=512 every pass has dozens) may step
-        the other way; every element with a gradient clearly above that level must take the oracle's step."""
+        the other way; every element with a gradient clearly above that level must take the oracle's step.  ``ties``
+        = LeakyReLU inputs of the oracle's pass within fp32 noise of 0 (TieWatch): each may flip one unit of one
+        sample, i.e. perturb the weight row feeding that unit (fan-in <= 4096) by 1/B of a per-sample gradient."""
         wo = torch.cat([p.detach().reshape(-1).double() for m in mods_o for p in m.parameters()])
         wp = torch.cat([p.detach().reshape(-1).double().cpu() for m in mods_p for p in m.parameters()])
         err = ((wp - before) - (wo - before)).abs()
@@ -353,7 +355,7 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
                 n_big += int(big.sum())
                 bad_big += int((err[off:off + n][big] > 0.05 * lr).sum())
                 off += n
-        assert bad_big <= 1e-4 * n_big, (what, bad_big, n_big)
+        assert bad_big <= 1e-4 * n_big + 4096 * ties, (what, bad_big, n_big, ties)
 
     def weights(mods):
         return torch.cat([p.detach().reshape(-1).double() for m in mods for p in m.parameters()])
@@ -364,7 +366,7 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
         tape = orc.MaskTape()
         stepper.load_state(Eo, Go, Do, oe, od)
         # ---- oracle, phase 1 (mnist.py:224-230)
-        with orc.use_tape(tape):
+        with orc.use_tape(tape), TieWatch(Eo, Go, Do) as tw:
             w_eg = weights((Eo, Go))
             oe.zero_grad()
             l_eg = (bce(Do(images, Eo(images, c), c), fake) + bce(Do(Go(z, c), z, c), valid)) / 2
@@ -377,11 +379,11 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
             stepper._phase_eg(cx)
         assert abs(cx["out"]["loss_eg"].item() - l_eg.item()) <= 1e-5 * max(1, abs(l_eg.item()))
         assert _rel(stepper.opt_eg.grad.double().cpu(), g_eg) <= 2e-3, (i, "EG grads")
-        check_update((Eo, Go), (E, G), w_eg, g_eg, f"EG update {i}")
+        check_update((Eo, Go), (E, G), w_eg, g_eg, f"EG update {i}", tw.ties)
         # ---- phase 2 (mnist.py:232-236) from the oracle's post-EG state
         stepper.load_state(Eo, Go, Do, oe, od)
         n0 = len(tape.masks)
-        with orc.use_tape(tape):
+        with orc.use_tape(tape), TieWatch(Eo, Do) as tw:
             w_d = weights((Do,))
             od.zero_grad()
             Eo.zero_grad(), Go.zero_grad()
@@ -393,11 +395,11 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
             stepper._phase_d_real(cx)
         assert abs(cx["out"]["loss_d_real"].item() - l_dr.item()) <= 1e-5 * max(1, abs(l_dr.item()))
         assert _rel(stepper.opt_d.grad.double().cpu(), g_d) <= 2e-3, (i, "D real grads")
-        check_update((Do,), (D,), w_d, g_d, f"D real update {i}")
+        check_update((Do,), (D,), w_d, g_d, f"D real update {i}", tw.ties)
         # ---- phase 3 (mnist.py:237-241)
         stepper.load_state(Eo, Go, Do, oe, od)
         n0 = len(tape.masks)
-        with orc.use_tape(tape):
+        with orc.use_tape(tape), TieWatch(Go, Do) as tw:
             w_d = weights((Do,))
             od.zero_grad()
             l_df = bce(Do(Go(z, c), z, c), fake)
@@ -408,7 +410,7 @@ def test_hand_scheduled_stepper_vs_oracle(rescale, bs):
             stepper._phase_d_fake(cx)
         assert abs(cx["out"]["loss_d_fake"].item() - l_df.item()) <= 1e-5 * max(1, abs(l_df.item()))
         assert _rel(stepper.opt_d.grad.double().cpu(), g_d) <= 2e-3, (i, "D fake grads")
-        check_update((Do,), (D,), w_d, g_d, f"D fake update {i}")
+        check_update((Do,), (D,), w_d, g_d, f"D fake update {i}", tw.ties)
         # ---- phase 4 (mnist.py:243-248)
         stepper.load_state(Eo, Go, Do, oe, od)
         n0 = len(tape.masks)
