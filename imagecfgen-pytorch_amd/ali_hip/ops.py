@@ -456,6 +456,69 @@ def bce_logits(logit, target, gscale=1.0, want_grad=True):
     return out2, gl
 
 
+def bce_logits_pair(logit, B, target_a, target_b, gscale=1.0, want_grad=True):
+    """BCE of two passes batched along the rows ([0,B) vs target_a, [B,2B) vs target_b) in one launch.
+    Returns (out3 = [(loss_a+loss_b)/2, mean sigmoid(a), mean sigmoid(b)], glogit [2B,1] or None)."""
+    lib = _lib.load()
+    assert logit.numel() == 2 * B
+    out3 = torch.empty(3, dtype=torch.float32, device=logit.device)
+    gl = torch.empty_like(logit) if want_grad else None
+    _lib.check(lib.ali_bce_logits_pair(_chk(logit, "logit"), B, float(target_a), float(target_b), float(gscale),
+                                       _chk(out3), _opt(gl), _stream()), "ali_bce_logits_pair")
+    return out3, gl
+
+
+def _attr_arrays(tensors):
+    """ctypes views of a list of [B, n] one-hot tensors (fp32 or int32, contiguous CUDA)."""
+    n = len(tensors)
+    for t in tensors:
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.int32) and t.dim() == 2):
+            raise ValueError(f"categorical attribute: need a contiguous [B, n] fp32 / int32 CUDA tensor, got "
+                             f"{t.dtype} {tuple(t.shape)}")
+    ptrs = (c_void_p * max(n, 1))(*[t.data_ptr() for t in tensors])
+    ncls = (ctypes.c_int32 * max(n, 1))(*[t.shape[1] for t in tensors])
+    isint = (ctypes.c_int32 * max(n, 1))(*[int(t.dtype == torch.int32) for t in tensors])
+    return ptrs, ncls, isint
+
+
+def attr_pack(cats, conts, B, device):
+    """arg-max class of every categorical attribute -> idx [B, n_cat] int32; continuous attributes ([B] / [B,1] fp32)
+    -> cont [B, n_cont] (or None).  One launch (include/ali_hip.h: ali_attr_pack)."""
+    lib = _lib.load()
+    ptrs, ncls, isint = _attr_arrays(cats)
+    idx = torch.empty(B, max(len(cats), 1), dtype=torch.int32, device=device)
+    for t in conts:
+        _chk(t, "continuous attribute")
+    cptr = (c_void_p * max(len(conts), 1))(*[t.data_ptr() for t in conts])
+    cont = torch.empty(B, len(conts), dtype=torch.float32, device=device) if conts else None
+    _lib.check(lib.ali_attr_pack(ptrs, ncls, isint, len(cats), cptr, len(conts), B, c_void_p(idx.data_ptr()),
+                                 None if cont is None else c_void_p(cont.data_ptr()), _stream()), "ali_attr_pack")
+    return idx, cont
+
+
+def g_input(z, onehots, tables, cont, ld):
+    """Generator input rows [B, ld] = [z | onehot_j @ table_j | cont | 0] in one launch (ali_g_input)."""
+    lib = _lib.load()
+    B, zdim = z.shape
+    ptrs, ncls, isint = _attr_arrays(onehots)
+    for t in tables:
+        _chk(t, "embedding table")
+    tptr = (c_void_p * max(len(tables), 1))(*[t.data_ptr() for t in tables])
+    out = torch.empty(B, ld, dtype=torch.float32, device=z.device)
+    _lib.check(lib.ali_g_input(_chk(z, "z"), zdim, ptrs, ncls, isint, tptr, len(tables), _opt(cont, "cont"),
+                               0 if cont is None else cont.shape[1], B, ld, _chk(out), _stream()), "ali_g_input")
+    return out
+
+
+def g_input_table_grad(onehot, g, off, out):
+    """out [n_classes, 256] = onehot^T @ g[:, off:off+256]  (ali_g_input_table_grad)."""
+    lib = _lib.load()
+    ptrs, ncls, isint = _attr_arrays([onehot])
+    _lib.check(lib.ali_g_input_table_grad(c_void_p(onehot.data_ptr()), isint[0], ncls[0], _chk(g, "g"), g.shape[1], off,
+                                          g.shape[0], _chk(out, "out"), _stream()), "ali_g_input_table_grad")
+    return out
+
+
 def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0):
     lib = _lib.load()
     ds = None

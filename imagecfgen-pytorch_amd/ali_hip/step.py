@@ -89,11 +89,11 @@ class MnistFamily:
 
     @staticmethod
     def conditioning(c):
+        """(arg-max class index [B,1] int32, continuous attributes [B,n] in sorted key order, one-hot tensors)"""
         keys = sorted(k for k in c if k != "digit")
         B = c["digit"].shape[0]
-        idx = c["digit"].argmax(1).to(torch.int32).reshape(B, 1).contiguous()
-        cont = torch.cat([c[k].reshape(B, 1).float() for k in keys], dim=1).contiguous() if keys else None
-        onehots = [c["digit"].float()]
+        onehots = [_attr2d(c["digit"], B)]
+        idx, cont = ops.attr_pack(onehots, [_attr2d(c[k], B, True) for k in keys], B, onehots[0].device)
         return idx, cont, onehots
 
     @staticmethod
@@ -117,9 +117,9 @@ class SpectFamily:
 
     def conditioning(self, c):
         B = c[self.cat_keys[0]].shape[0]
-        idx = torch.stack([c[k].argmax(dim=1) for k in self.cat_keys], dim=1).to(torch.int32).contiguous()
-        cont = c[self.cont_key].reshape(B, 1).float().contiguous() if self.cont_key is not None else None
-        onehots = [c[k].float() for k in self.cat_keys]
+        onehots = [_attr2d(c[k], B) for k in self.cat_keys]
+        conts = [_attr2d(c[self.cont_key], B, True)] if self.cont_key is not None else []
+        idx, cont = ops.attr_pack(onehots, conts, B, onehots[0].device)
         return idx, cont, onehots
 
     def used(self, c):
@@ -127,6 +127,23 @@ class SpectFamily:
         (finetune_whale_bigan.py:63-64: 'audio', 'path', 'time')"""
         keys = self.cat_keys + ((self.cont_key,) if self.cont_key is not None else ())
         return {k: c[k] for k in keys}
+
+
+def _attr2d(t, B, as_float=False):
+    """attribute tensor as the kernels take it: contiguous [B, n], fp32 (or int32 one-hots, whalecalls.py:455)"""
+    if t.dtype != torch.float32 and (as_float or t.dtype != torch.int32):
+        t = t.float()
+    return t.reshape(B, -1).contiguous()
+
+
+def _g_input(fam, z, onehots, cont):
+    """[z | onehot @ table ... | cont | 0 pad] rows of the Generator's first layer (mnist.py:76-85), one launch;
+    channel stride % 32 == 0 -> uniform-tap fast path of the GEMM kernel.  Returns ([B,1,1,ld], logical width)."""
+    B = z.shape[0]
+    z = z.reshape(B, -1).float().contiguous()
+    n_log = z.shape[1] + 256 * len(fam.g_tables) + (0 if cont is None else cont.shape[1])
+    ld = n_log + (-n_log) % 32
+    return ops.g_input(z, onehots, [t.detach() for t in fam.g_tables], cont, ld).reshape(B, 1, 1, ld), n_log
 
 
 def family_of(E, G, D):
@@ -187,15 +204,7 @@ class AliStepper:
             ops.plane_table_grad(g0, gofs + j, x0, 1 + j, idx, j, t.shape[0], out=dst[id(t)])
 
     def _g_input(self, z, onehots, cont):
-        B = z.shape[0]
-        feats = [z.reshape(B, -1).float()] + [oh.matmul(t.detach()) for oh, t in zip(onehots, self.family.g_tables)]
-        if cont is not None:
-            feats.append(cont)
-        n_log = sum(f.shape[1] for f in feats)
-        pad = (-n_log) % 32          # channel stride % 32 == 0 -> uniform-tap fast path of the GEMM kernel
-        if pad:
-            feats.append(torch.zeros(B, pad, device=z.device))
-        return torch.cat(feats, dim=1).reshape(B, 1, 1, n_log + pad), n_log
+        return _g_input(self.family, z, onehots, cont)
 
     def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None):
         B = x0.shape[0]
@@ -213,7 +222,7 @@ class AliStepper:
         B = x0.shape[0] // 2
         with _dropout.paired_passes(self._n_drop):
             logit, saved = self._d_forward(x0, n_log, torch.cat([zina, zinb], dim=0), save, 2)
-        return logit[:B], logit[B:], saved
+        return logit, saved
 
     def _d_backward(self, saved, glogit, need_params, need_x, need_z, planes=None):
         s_dx, s_dz, s_dxz, n_dx, n_log = saved
@@ -252,14 +261,13 @@ class AliStepper:
         gz, sG = chain_forward(self.pG, gin, True, g_log, True)
         # D(x, E(x)) and D(G(z), z) share the weights: one batch of 2B samples (reference order: real pass first)
         x0p, _ = self._planes_pair(images, gz, idx, cont, fam.d_tables)
-        d_valid, d_fake, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(None, ex.reshape(zin.shape), None, zin,
-                                                                             n_log, True, x0_pair=x0p)
-        l1, gl1 = ops.bce_logits(d_valid.contiguous(), 0.0, 0.5)
-        l2, gl2 = ops.bce_logits(d_fake.contiguous(), 1.0, 0.5)
-        cx["out"]["loss_eg"] = (l1[0] + l2[0]) / 2
+        logits, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(None, ex.reshape(zin.shape), None, zin, n_log, True,
+                                                                    x0_pair=x0p)
+        # (bce(D_valid, 0) + bce(D_fake, 1)) / 2 and its gradient for both halves: one launch
+        l3, gl = ops.bce_logits_pair(logits, B, 0.0, 1.0, 0.5)
+        cx["out"]["loss_eg"] = l3[0]
         # backward: dxz for both passes at once (data gradient only: D is not updated in this phase) ...
-        gjoint, _ = chain_backward(self.pDxz, s_dxz, torch.cat([gl1, gl2], dim=0).reshape(2 * B, 1, 1, 1),
-                                   s_dxz[0].in_shape[3], True, False)
+        gjoint, _ = chain_backward(self.pDxz, s_dxz, gl.reshape(2 * B, 1, 1, 1), s_dxz[0].in_shape[3], True, False)
         gjoint = gjoint.reshape(2 * B, -1)
         dst = self.opt_eg.grad_views
         # ... real pass: only the z-side path (dxz -> dz) reaches E
@@ -279,7 +287,7 @@ class AliStepper:
         g_gin = g_gin.reshape(B, -1)
         off = zin.shape[1]
         for oh, t in zip(onehots, fam.g_tables):
-            dst[id(t)].copy_(oh.t().matmul(g_gin[:, off:off + 256]))
+            ops.g_input_table_grad(oh, g_gin, off, dst[id(t)])
             off += 256
 
     def _apply_eg(self):
@@ -355,9 +363,9 @@ class AliStepper:
         re-using G'(z) and E'(x) of the D phases (the reference recomputes identical values)."""
         fam, images, idx, cont, zin = self.family, cx["images"], cx["idx"], cx["cont"], cx["zin"]
         x0p, _ = self._planes_pair(cx["gz"], images, idx, cont, fam.d_tables)
-        dg, de, _ = self._d_forward_pair(None, zin, None, cx["ex"].reshape(zin.shape), cx["n_log"], False, x0_pair=x0p)
-        cx["out"]["dg"] = ops.bce_logits(dg.contiguous(), 0.0, 1.0, want_grad=False)[0][1]
-        cx["out"]["de"] = ops.bce_logits(de.contiguous(), 0.0, 1.0, want_grad=False)[0][1]
+        logits, _ = self._d_forward_pair(None, zin, None, cx["ex"].reshape(zin.shape), cx["n_log"], False, x0_pair=x0p)
+        s3 = ops.bce_logits_pair(logits, cx["B"], 0.0, 0.0, 1.0, want_grad=False)[0]
+        cx["out"]["dg"], cx["out"]["de"] = s3[1], s3[2]
         _dropout.end_iteration()
         _chain.flush_batch_counts()        # all BatchNorm num_batches_tracked increments of the iteration: one launch
         if self.dist and average_bn:
@@ -654,14 +662,7 @@ class FinetuneStepper:
                                  cont, B, H, W, (n_log + 3) // 4 * 4)
         codes, sE = chain_forward(self.pE, x0, self.E.training, n_log, True)
         zin = codes.reshape(B, -1)
-        feats = [zin] + [oh.matmul(t.detach()) for oh, t in zip(onehots, fam.g_tables)]
-        if cont is not None:
-            feats.append(cont)
-        g_log = sum(f.shape[1] for f in feats)
-        pad = (-g_log) % 32
-        if pad:
-            feats.append(torch.zeros(B, pad, device=x.device))
-        gin = torch.cat(feats, dim=1).reshape(B, 1, 1, -1)
+        gin, g_log = _g_input(fam, zin, onehots, cont)
         xr, sG = chain_forward(self.pG, gin, self.G.training, g_log, True)
         xf, xrf = x.reshape(B, -1).float(), xr.reshape(B, -1)
         if pairwise:

@@ -5,6 +5,7 @@
 // in include/ali_hip.h.  All reductions are deterministic (fixed partial slabs,
 // fixed summation order; no float atomics).
 #include "ali_common.h"
+#include <string.h>
 
 namespace ali {
 
@@ -193,24 +194,34 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, const float
 // partial (b, s, c) of group gi lives at part[gi*lay.g + b*lay.b + s*lay.s + c*lay.c]: [nblk][2][C] blocks per group for
 // the reduction kernels above, [2][C][slots] (slots of a group contiguous) for partials left by a convolution epilogue
 struct PartLayout { long long g, b, s, c; };
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, PartLayout lay, int nblk, int C, long long count,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                      float momentum, float eps, int training, float* __restrict__ mean_out,
-                                      float* __restrict__ invstd_out, float* __restrict__ sc, float* __restrict__ sh,
-                                      int groups, long long stat_stride) {
-  const int c = blockIdx.x;   // one wave per channel; the groups (batched passes) update the running stats in order
+// fixed-order sum of a block's per-thread doubles (256 threads): thread 0 gets the total
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+  __syncthreads();
+  return tot;
+}
+__global__ void __launch_bounds__(kEwBlock)
+bn_stats_final_kernel(const float* __restrict__ part, PartLayout lay, int nblk, int C, long long count,
+                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                      float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                      int training, float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ sc,
+                      float* __restrict__ sh, int groups, long long stat_stride) {
+  __shared__ double red[8];
+  const int c = blockIdx.x;   // one block per channel; the groups (batched passes) update the running stats in order
   for (int gi = 0; gi < groups; ++gi) {
     const float* pg = part + (long long)gi * lay.g + (long long)c * lay.c;
     float mean, var;
     if (training) {
       double s1 = 0.0, s2 = 0.0;
-      for (int b = threadIdx.x; b < nblk; b += 64) {
+      for (int b = threadIdx.x; b < nblk; b += kEwBlock) {
         s1 += (double)pg[(long long)b * lay.b];
         s2 += (double)pg[(long long)b * lay.b + lay.s];
       }
-      s1 = wave_sum(s1);
-      s2 = wave_sum(s2);
+      s1 = block_sum_256(s1, red);
+      s2 = block_sum_256(s2, red + 4);
       const double m = s1 / (double)count;
       double v = s2 / (double)count - m * m;
       if (v < 0.0) v = 0.0;
@@ -291,17 +302,19 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
     part[((long long)blockIdx.x * 2 + 1) * C + tc] = red2[t];
   }
 }
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, PartLayout lay, int nblk, int C,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x;   // one wave per channel
+__global__ void __launch_bounds__(kEwBlock)
+bn_bwd_final_kernel(const float* __restrict__ part, PartLayout lay, int nblk, int C, float* __restrict__ dgamma,
+                    float* __restrict__ dbeta) {
+  __shared__ double red[8];
+  const int c = blockIdx.x;   // one block per channel
   double s1 = 0.0, s2 = 0.0;
   const float* pg = part + (long long)c * lay.c;
-  for (int b = threadIdx.x; b < nblk; b += 64) {
+  for (int b = threadIdx.x; b < nblk; b += kEwBlock) {
     s1 += (double)pg[(long long)b * lay.b];
     s2 += (double)pg[(long long)b * lay.b + lay.s];
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red + 4);
   if (threadIdx.x == 0) {
     dgamma[c] = (float)s1;
     dbeta[c] = (float)s2;
@@ -663,6 +676,99 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+
+// ---- attribute plumbing of an iteration (replaces a dozen tiny ATen launches): arg-max class of every categorical
+// attribute + the continuous attributes gathered into one [B][n_cont] row (mnist.py:47-55,204-209; audio_mnist.py:203-210)
+struct AttrPtrs { const void* cat[8]; int ncls[8]; int is_int[8]; const float* cont[4]; };
+__device__ __forceinline__ float attr_val(const void* p, int is_int, long long i) {
+  return is_int ? (float)reinterpret_cast<const int*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__global__ void attr_pack_kernel(AttrPtrs a, int n_cat, int n_cont, int B, int* __restrict__ idx, float* __restrict__ cont) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int j = 0; j < n_cat; ++j) {     // torch.argmax: first maximal entry
+    int best = 0;
+    float bv = attr_val(a.cat[j], a.is_int[j], (long long)b * a.ncls[j]);
+    for (int n = 1; n < a.ncls[j]; ++n) {
+      const float v = attr_val(a.cat[j], a.is_int[j], (long long)b * a.ncls[j] + n);
+      if (v > bv) { bv = v; best = n; }
+    }
+    idx[b * n_cat + j] = best;
+  }
+  for (int j = 0; j < n_cont; ++j) cont[b * n_cont + j] = a.cont[j][b];
+}
+
+// Generator input row (mnist.py:76-85, audio_mnist.py:250-256): [ z | onehot_j @ table_j (256 each) | cont | 0 pad ].
+// The product stays a true sum over classes, so soft (non one-hot) attributes give what the reference's matmul gives.
+struct GInPtrs { const void* oh[8]; const float* tab[8]; int ncls[8]; int is_int[8]; };
+__global__ void g_input_kernel(const float* __restrict__ z, int zdim, GInPtrs p, int n_emb, const float* __restrict__ cont,
+                               int n_cont, int B, int ld, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  float* o = out + (long long)b * ld;
+  for (int c = threadIdx.x; c < ld; c += blockDim.x) {
+    float v = 0.f;
+    if (c < zdim) v = z[(long long)b * zdim + c];
+    else if (c < zdim + 256 * n_emb) {
+      const int j = (c - zdim) >> 8, k = (c - zdim) & 255;
+      for (int n = 0; n < p.ncls[j]; ++n) {
+        const float w = attr_val(p.oh[j], p.is_int[j], (long long)b * p.ncls[j] + n);
+        if (w != 0.f) v += w * p.tab[j][n * 256 + k];
+      }
+    } else if (c < zdim + 256 * n_emb + n_cont) v = cont[b * n_cont + (c - zdim - 256 * n_emb)];
+    o[c] = v;
+  }
+}
+// its table gradient: dT[n][k] = sum_b onehot[b][n] * g[b*ld + off + k].  Block = (class n, 16 columns k): 16 sample
+// lanes x 16 columns, each lane sums its samples b = lane, lane+16, ... in order, the lanes are combined in order.
+__global__ void __launch_bounds__(256)
+g_input_table_grad_kernel(const void* __restrict__ oh, int is_int, int ncls, const float* __restrict__ g, int ld, int off,
+                          int B, float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int n = blockIdx.x >> 4, k = ((blockIdx.x & 15) << 4) + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int b = sl; b < B; b += 16)
+    acc += attr_val(oh, is_int, (long long)b * ncls + n) * g[(long long)b * ld + off + k];
+  red[sl][threadIdx.x & 15] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += red[j][threadIdx.x];
+    out[n * 256 + ((blockIdx.x & 15) << 4) + threadIdx.x] = v;
+  }
+}
+
+// BCE-with-logits of two passes batched along the rows ([0,B): target ta, [B,2B): target tb), e.g. the E+G loss
+// (bce(D(x,E(x)),0) + bce(D(G(z),z),1)) / 2 of mnist.py:228 or the two scores of :245-248, in one launch:
+// out[0] = (loss_a + loss_b) / 2, out[1] = mean sigmoid(a), out[2] = mean sigmoid(b); glogit = gscale*(sigmoid - t)/B
+__global__ void bce_logits_pair_kernel(const float* __restrict__ logit, int B, float ta, float tb, float gscale,
+                                       float* __restrict__ out3, float* __restrict__ glogit) {
+  __shared__ double r1[kEwBlock], r2[kEwBlock], r3[kEwBlock], r4[kEwBlock];
+  const int t = threadIdx.x;
+  double la = 0.0, lb = 0.0, sa = 0.0, sb = 0.0;
+  for (int i = t; i < 2 * B; i += kEwBlock) {
+    const float x = logit[i];
+    const float tg = i < B ? ta : tb;
+    const float loss = fmaxf(x, 0.f) - x * tg + log1pf(expf(-fabsf(x)));
+    const float s = 1.f / (1.f + expf(-x));
+    if (i < B) { la += (double)loss; sa += (double)s; } else { lb += (double)loss; sb += (double)s; }
+    if (glogit) glogit[i] = gscale * (s - tg) / (float)B;
+  }
+  r1[t] = la; r2[t] = lb; r3[t] = sa; r4[t] = sb;
+  __syncthreads();
+  for (int off = kEwBlock / 2; off > 0; off >>= 1) {
+    if (t < off) { r1[t] += r1[t + off]; r2[t] += r2[t + off]; r3[t] += r3[t + off]; r4[t] += r4[t + off]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    // (a + b) / 2 on the two fp32 means, as the reference computes it
+    out3[0] = ((float)(r1[0] / B) + (float)(r2[0] / B)) / 2.f;
+    out3[1] = (float)(r3[0] / B);
+    out3[2] = (float)(r4[0] / B);
+  }
+}
+
 struct EmbPtrs { const float* t[8]; };
 __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* __restrict__ idx, EmbPtrs emb, int n_emb,
                                        const float* __restrict__ cont, int n_cont, float* __restrict__ out, int B,
@@ -836,7 +942,7 @@ extern "C" int ali_bn_stats(const float* x, const float* mask, int32_t B, int32_
       hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x + (size_t)gi * rows * C,
                          mask ? mask + (size_t)gi * Bg * C : nullptr, rows, rows_per_img, C, part + (size_t)gi * nb * 2 * C);
   const PartLayout lay = {(long long)nb * 2 * C, 2LL * C, (long long)C, 1LL};
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, nb, C, rows, gamma, beta,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(kEwBlock), 0, ST(stream), part, lay, nb, C, rows, gamma, beta,
                      running_mean, running_var, momentum, eps, training, mean, invstd, sc, sh, groups,
                      (long long)stat_stride);
   return check_launch("bn_stats");
@@ -853,7 +959,7 @@ extern "C" int ali_bn_stats_from_partials(const float* part, int32_t slots, int3
   }
   const int per = slots / groups;
   const PartLayout lay = {(long long)per, 1LL, (long long)C * slots, (long long)slots};
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, per, C, (long long)count, gamma,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(kEwBlock), 0, ST(stream), part, lay, per, C, (long long)count, gamma,
                      beta, running_mean, running_var, momentum, eps, 1, mean, invstd, sc, sh, groups,
                      (long long)stat_stride);
   return check_launch("bn_stats_from_partials");
@@ -918,7 +1024,7 @@ extern "C" int ali_bn_bwd(const float* x, const float* g, const float* mask_in, 
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(kEwBlock), 0, ST(stream), x, g, mask_in, mask_pre, mean, invstd,
                        rows, rows_per_img, C, part);
   const PartLayout lay = {0LL, 2LL * C, (long long)C, 1LL};
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, nb, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(kEwBlock), 0, ST(stream), part, lay, nb, C, dgamma, dbeta);
   if (gx) launch_bn_bwd_apply(x, g, mask_in, mask_pre, mean, invstd, gamma, dgamma, dbeta, rows, rows_per_img, C,
                               batch_stats, lrelu_slope, gx, vec, ST(stream));
   return check_launch("bn_bwd");
@@ -938,7 +1044,7 @@ extern "C" int ali_bn_bwd_from_partials(const float* part, int32_t slots, const 
                    (!mask_in || aligned16(mask_in)) && (!mask_pre || aligned16(mask_pre)) && aligned16(mean) &&
                    aligned16(invstd);
   const PartLayout lay = {0LL, 1LL, (long long)C * slots, (long long)slots};
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, ST(stream), part, lay, slots, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(kEwBlock), 0, ST(stream), part, lay, slots, C, dgamma, dbeta);
   if (gx) launch_bn_bwd_apply(x, g, mask_in, mask_pre, mean, invstd, gamma, dgamma, dbeta, rows, rows_per_img, C,
                               batch_stats, lrelu_slope, gx, vec, ST(stream));
   return check_launch("bn_bwd_from_partials");
@@ -1000,6 +1106,58 @@ extern "C" int ali_bce_logits(const float* logit, int32_t B, float target, float
   if (!logit || B <= 0) { set_error("ali_bce_logits: bad argument"); return ALI_ERR_BAD_ARG; }
   hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(kEwBlock), 0, ST(stream), logit, B, target, gscale, out2, glogit);
   return check_launch("bce_logits_kernel");
+}
+
+extern "C" int ali_attr_pack(const void* const* cat, const int32_t* n_classes, const int32_t* cat_is_int, int32_t n_cat,
+                             const float* const* cont_in, int32_t n_cont, int32_t B, int32_t* idx, float* cont,
+                             ali_stream_t stream) {
+  if (n_cat < 0 || n_cat > 8 || n_cont < 0 || n_cont > 4 || B <= 0 || (n_cat && (!cat || !n_classes || !idx)) ||
+      (n_cont && (!cont_in || !cont))) {
+    set_error("ali_attr_pack: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  AttrPtrs a;
+  memset(&a, 0, sizeof(a));
+  for (int j = 0; j < n_cat; ++j) { a.cat[j] = cat[j]; a.ncls[j] = n_classes[j]; a.is_int[j] = cat_is_int ? cat_is_int[j] : 0; }
+  for (int j = 0; j < n_cont; ++j) a.cont[j] = cont_in[j];
+  hipLaunchKernelGGL(attr_pack_kernel, dim3((B + 255) / 256), dim3(256), 0, ST(stream), a, n_cat, n_cont, B, idx, cont);
+  return check_launch("attr_pack_kernel");
+}
+
+extern "C" int ali_g_input(const float* z, int32_t zdim, const void* const* onehot, const int32_t* n_classes,
+                           const int32_t* onehot_is_int, const float* const* tables, int32_t n_emb, const float* cont,
+                           int32_t n_cont, int32_t B, int32_t ld, float* out, ali_stream_t stream) {
+  if (!z || !out || zdim <= 0 || n_emb < 0 || n_emb > 8 || n_cont < 0 || B <= 0 || ld < zdim + 256 * n_emb + n_cont ||
+      (n_emb && (!onehot || !n_classes || !tables)) || (n_cont && !cont)) {
+    set_error("ali_g_input: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  GInPtrs p;
+  memset(&p, 0, sizeof(p));
+  for (int j = 0; j < n_emb; ++j) {
+    p.oh[j] = onehot[j]; p.tab[j] = tables[j]; p.ncls[j] = n_classes[j]; p.is_int[j] = onehot_is_int ? onehot_is_int[j] : 0;
+  }
+  hipLaunchKernelGGL(g_input_kernel, dim3(B), dim3(256), 0, ST(stream), z, zdim, p, n_emb, cont, n_cont, B, ld, out);
+  return check_launch("g_input_kernel");
+}
+
+extern "C" int ali_g_input_table_grad(const void* onehot, int32_t onehot_is_int, int32_t n_classes, const float* g,
+                                      int32_t ld, int32_t off, int32_t B, float* out, ali_stream_t stream) {
+  if (!onehot || !g || !out || n_classes <= 0 || B <= 0 || off < 0 || off + 256 > ld) {
+    set_error("ali_g_input_table_grad: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(g_input_table_grad_kernel, dim3(n_classes * 16), dim3(256), 0, ST(stream), onehot, onehot_is_int,
+                     n_classes, g, ld, off, B, out);
+  return check_launch("g_input_table_grad_kernel");
+}
+
+extern "C" int ali_bce_logits_pair(const float* logit, int32_t B, float target_a, float target_b, float gscale,
+                                   float* out3, float* glogit, ali_stream_t stream) {
+  if (!logit || !out3 || B <= 0) { set_error("ali_bce_logits_pair: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(bce_logits_pair_kernel, dim3(1), dim3(kEwBlock), 0, ST(stream), logit, B, target_a, target_b, gscale,
+                     out3, glogit);
+  return check_launch("bce_logits_pair_kernel");
 }
 
 extern "C" int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -229,6 +229,28 @@ int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, fl
 int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
              float eps, int32_t step, const int32_t* dev_step, float grad_scale, ali_stream_t stream);
 
+/* BCEWithLogitsLoss of two passes batched along the rows, rows [0,B) against target_a and [B,2B) against target_b
+ * (mnist.py:228: (bce(D_valid, 0) + bce(D_fake, 1)) / 2; :245-248: the two sigmoid().mean() scores):
+ * out3 = {(loss_a + loss_b)/2, mean sigmoid(a), mean sigmoid(b)}; glogit[i] = gscale*(sigmoid - target)/B or NULL. */
+int ali_bce_logits_pair(const float* logit, int32_t B, float target_a, float target_b, float gscale, float* out3,
+                        float* glogit, ali_stream_t stream);
+
+/* Attribute plumbing of one batch (mnist.py:47-55, audio_mnist.py:203-210, whalecalls.py:455): idx[b*n_cat + j] =
+ * argmax of categorical attribute j (one-hot rows of n_classes[j] floats, or int32 when cat_is_int[j]; first maximum
+ * like torch.argmax); cont[b*n_cont + j] = cont_in[j][b]. */
+int ali_attr_pack(const void* const* cat, const int32_t* n_classes, const int32_t* cat_is_int, int32_t n_cat,
+                  const float* const* cont_in, int32_t n_cont, int32_t B, int32_t* idx, float* cont, ali_stream_t stream);
+
+/* Generator input (mnist.py:76-85; audio_mnist.py:250-256): out[b*ld + :] = [ z[b, :zdim] | onehot_j[b] @ tables[j]
+ * ([n_classes[j]][256]) for j < n_emb | cont[b, :n_cont] | zeros ] -- a true sum over classes (soft attributes), the
+ * zero padding brings the row to the GEMM's channel stride.  ali_g_input_table_grad: the gradient of one table,
+ * out[n][k] = sum_b onehot[b][n] * g[b*ld + off + k] (samples in order, no atomics). */
+int ali_g_input(const float* z, int32_t zdim, const void* const* onehot, const int32_t* n_classes,
+                const int32_t* onehot_is_int, const float* const* tables, int32_t n_emb, const float* cont, int32_t n_cont,
+                int32_t B, int32_t ld, float* out, ali_stream_t stream);
+int ali_g_input_table_grad(const void* onehot, int32_t onehot_is_int, int32_t n_classes, const float* g, int32_t ld,
+                           int32_t off, int32_t B, float* out, ali_stream_t stream);
+
 /* Conditioning-plane assembly (mnist.py:24-29,46-55; audio_mnist.py:178-209):
  * out[b,h,w,0] = X[b,h,w]; out[..,1+j] = tanh(emb_j[idx_j[b]][src(h,w)]) for the
  * n_emb categorical planes (16x16 tables, nearest up-sampling, src = floor(dst*16/H));
