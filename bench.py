@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--workload", default="mnist", choices=["mnist", "audio", "whale", "esrf"],
                     help="mnist = BASELINE.json configs[1] (the headline metric); the others are configs[2..4]")
     ap.add_argument("--mode", default="stepper", choices=["stepper", "autograd"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+                    help="f16 = fp16-MFMA forward / data-gradient GEMMs with fp32 accumulation (BASELINE config 5: esrf)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -154,7 +156,7 @@ def main():
     betas = (0.5, 0.999) if args.workload == "mnist" else (0.5, 0.9)
 
     if args.mode == "stepper":
-        stepper = AliStepper(E, G, D, betas=betas, process_group=pg, capture=not args.no_graph)
+        stepper = AliStepper(E, G, D, betas=betas, process_group=pg, capture=not args.no_graph, precision=args.precision)
 
         def one(i):
             images, c, z = batches[i % len(batches)]
@@ -253,7 +255,7 @@ def main():
             "value": round(value, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{names[args.workload]} synthetic, bs={bs}/GPU, fp32 MFMA, mode={args.mode}"
                                    f"{'' if args.no_graph or args.mode != 'stepper' else ('+hipgraph' if world == 1 else '+hipgraph-segments')}",
                        "global_batch": bs * world, "parallelism": f"dp{world}"},

@@ -25,7 +25,7 @@ class AliEpilogue(Structure):
                 # fused BatchNorm reductions (include/ali_hip.h)
                 ("bn_part", c_void_p), ("bn_mode", c_int32), ("bn_groups", c_int32), ("bn_stat_mask", c_void_p),
                 ("bn_mask_ld", c_int32), ("bn_x", c_void_p), ("bn_mean", c_void_p), ("bn_invstd", c_void_p),
-                ("bn_mask_in", c_void_p), ("bn_mask_pre", c_void_p)]
+                ("bn_mask_in", c_void_p), ("bn_mask_pre", c_void_p), ("mfma_f16", c_int32)]
 
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
@@ -33,7 +33,7 @@ ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
 # name -> (restype, argtypes); every symbol include/ali_hip.h declares
 SIGNATURES = {
     "ali_conv_workspace_bytes": (c_size_t, [POINTER(AliConvGeom), c_int32]),
-    "ali_conv_mtiles": (c_int32, [POINTER(AliConvGeom), c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    "ali_conv_mtiles": (c_int32, [POINTER(AliConvGeom), c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "ali_conv_fwd": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue), c_void_p,
                                c_size_t, c_void_p]),
     "ali_conv_bwd_data": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue),

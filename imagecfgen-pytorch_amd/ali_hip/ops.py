@@ -47,6 +47,27 @@ def _opt(t, name="tensor"):
     return None if t is None else _chk(t, name)
 
 
+_PRECISION = {"f16": False}
+
+
+class precision:
+    """``with ops.precision("f16"):`` -- the GEMMs launched inside run their contraction on fp16 MFMA
+    (v_mfma_f32_32x32x16_f16, fp32 accumulation; include/ali_hip.h: AliEpilogue.mfma_f16) where their fast path
+    applies; "f32" (default) is the exact fp32 MFMA everywhere."""
+
+    def __init__(self, name):
+        if name not in ("f32", "f16"):
+            raise ValueError(f"precision must be 'f32' or 'f16', got {name!r}")
+        self.f16 = name == "f16"
+
+    def __enter__(self):
+        self.prev, _PRECISION["f16"] = _PRECISION["f16"], self.f16
+        return self
+
+    def __exit__(self, *exc):
+        _PRECISION["f16"] = self.prev
+
+
 def geom(B, H, W, C, P, Q, K, R, S, stride, pad) -> AliConvGeom:
     return AliConvGeom(B, H, W, C, P, Q, K, R, S, stride, pad)
 
@@ -63,6 +84,7 @@ def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=AC
     ep.mask_ld = mask.shape[1] if mask is not None else 0
     ep.dact_y = _opt(dact_y, "dact_y")
     ep.dact, ep.dslope = dact, dslope
+    ep.mfma_f16 = int(_PRECISION["f16"])
     if bn_fwd is not None:
         part, groups, smask = bn_fwd
         ep.bn_part, ep.bn_mode, ep.bn_groups = _chk(part, "bn_part"), 1, groups
@@ -83,11 +105,12 @@ _MTILES = {}
 
 def conv_mtiles(g: AliConvGeom, which: int):
     """(M-tiles, tile rows, rows ordered (pixel, image)?) of the launch ali_conv_fwd (0) / ali_conv_bwd_data (1) makes."""
-    key = (which,) + tuple(getattr(g, n) for n, _ in AliConvGeom._fields_)
+    f16 = int(_PRECISION["f16"])
+    key = (which, f16) + tuple(getattr(g, n) for n, _ in AliConvGeom._fields_)
     hit = _MTILES.get(key)
     if hit is None:
         rows, pm = ctypes.c_int32(0), ctypes.c_int32(0)
-        n = _lib.load().ali_conv_mtiles(byref(g), which, byref(rows), byref(pm))
+        n = _lib.load().ali_conv_mtiles(byref(g), which, f16, byref(rows), byref(pm))
         hit = _MTILES[key] = (n, rows.value, bool(pm.value))
     return hit
 

@@ -152,8 +152,15 @@ def family_of(E, G, D):
 
 class AliStepper:
     def __init__(self, E, G, D, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, family=None, process_group=None,
-                 capture=False):
+                 capture=False, precision="f32", loss_scale=None):
+        """``precision="f16"``: the convolutions' forward and data-gradient GEMMs contract fp16 operands on
+        v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5); activations, master weights, weight
+        gradients' accumulation and Adam stay fp32.  The three losses' gradients are multiplied by ``loss_scale``
+        (default 1024 for f16, 1 otherwise; a power of two) so that small gradients survive the fp16 rounding of the
+        GEMM operands, and Adam divides it out again."""
         self.E, self.G, self.D = E, G, D
+        self.precision = precision
+        self.loss_scale = float(loss_scale if loss_scale is not None else (1024.0 if precision == "f16" else 1.0))
         self.family = family or family_of(E, G, D)
         self.pE, self.pG = get_plan(E.layers), get_plan(G.layers)
         self.pDx, self.pDz, self.pDxz = get_plan(D.dx), get_plan(D.dz), get_plan(D.dxz)
@@ -264,7 +271,7 @@ class AliStepper:
         logits, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(None, ex.reshape(zin.shape), None, zin, n_log, True,
                                                                     x0_pair=x0p)
         # (bce(D_valid, 0) + bce(D_fake, 1)) / 2 and its gradient for both halves: one launch
-        l3, gl = ops.bce_logits_pair(logits, B, 0.0, 1.0, 0.5)
+        l3, gl = ops.bce_logits_pair(logits, B, 0.0, 1.0, 0.5 * self.loss_scale)
         cx["out"]["loss_eg"] = l3[0]
         # backward: dxz for both passes at once (data gradient only: D is not updated in this phase) ...
         gjoint, _ = chain_backward(self.pDxz, s_dxz, gl.reshape(2 * B, 1, 1, 1), s_dxz[0].in_shape[3], True, False)
@@ -291,13 +298,13 @@ class AliStepper:
             off += 256
 
     def _apply_eg(self):
-        self.opt_eg.adam(1.0 / self.world)
+        self.opt_eg.adam(1.0 / (self.world * self.loss_scale))
         with ops.batched_packs():
             self.pE.cache.refresh()
             self.pG.cache.refresh()
 
     def _apply_d(self):
-        self.opt_d.adam(1.0 / self.world)
+        self.opt_d.adam(1.0 / (self.world * self.loss_scale))
         self._refresh_d()
 
     def _phase_eg(self, cx):
@@ -337,7 +344,7 @@ class AliStepper:
         x0e, _ = self._planes(images, idx, cont, fam.e_tables)
         ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
         d_valid, sD = self._d_forward(x0d, n_log, ex, True, dx_pre=cx.pop("dx_pre"))
-        l, gl = ops.bce_logits(d_valid, 1.0, 1.0)
+        l, gl = ops.bce_logits(d_valid, 1.0, self.loss_scale)
         cx["out"]["loss_d_real"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0d, idx, fam.d_tables, self.opt_d.grad_views)
@@ -353,7 +360,7 @@ class AliStepper:
         fam, idx, cont, zin = self.family, cx["idx"], cx["cont"], cx["zin"]
         x0f, _ = self._planes(cx["gz"], idx, cont, fam.d_tables)
         d_fake, sD = self._d_forward(x0f, cx["n_log"], zin, True)
-        l, gl = ops.bce_logits(d_fake, 0.0, 1.0)
+        l, gl = ops.bce_logits(d_fake, 0.0, self.loss_scale)
         cx["out"]["loss_d_fake"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
         self._plane_grads(g_x0, x0f, idx, fam.d_tables, self.opt_d.grad_views)
@@ -507,6 +514,10 @@ class AliStepper:
             _chain.abort_batch_counts()     # no-op after a completed iteration
 
     def _step(self, images, c, z, do_eg, masks):
+        with ops.precision(self.precision):
+            return self._step_impl(images, c, z, do_eg, masks)
+
+    def _step_impl(self, images, c, z, do_eg, masks):
         if masks is not None:
             with _dropout.injected_masks(masks):
                 return self._iteration(images, c, z, do_eg)

@@ -72,6 +72,7 @@ struct GDesc {
   int Hout, Wout, Cout, ldo;
   int ldw, S;          // weight row stride (floats), kernel width (taps per kernel row)
   int nphase, splitk, kt_per_split;
+  int f16;             // AliEpilogue.mfma_f16: fp16 operands on v_mfma_f32_32x32x16_f16 where the fast path applies
   unsigned in_bytes, w_bytes;
   long long out_elems;
   Phase ph[4];
@@ -90,7 +91,15 @@ __device__ __forceinline__ void fast_divmod(int m, int dv, float rcp, int& q, in
 // MODE 0: scalar gathers (channel stride % 4 != 0); 1: 16-byte gathers, tap per thread (division); 2: uniform-tap fast
 // path (channel stride % 32 == 0); 3: fast path for channel stride 4 / 8 / 16 (first layers): a k-tile holds 32/C whole
 // taps, the tap of a thread's 16-byte chunk is a shift, its constants a per-thread LDS read
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+// F16 (MODE 2 only): the fp16-MFMA variant (BASELINE config 5, esrf_acoustic.py:134-260).  Operands stay fp32 in HBM and
+// are rounded to fp16 (RNE) on their way into LDS; v_mfma_f32_32x32x16_f16 accumulates in fp32.  Same prologue, tap
+// skipping, split-K and epilogues as the fp32 kernel; the k-loop is a plain double-buffered one (a 32-cycle MFMA leaves
+// the vector issue free most of the time, unlike the 64-cycle fp32 one: no per-slot pinning needed).
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr int LDH = 40;      // fp16 LDS rows: 32 halves + 8 pad = 80 B (16-B aligned, ds_read_b128 conflict-free)
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -282,7 +291,83 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     };
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
-    if (qb < qe) {
+    if (F16) {
+      if (qb < qe) {
+        _Float16* Ah = reinterpret_cast<_Float16*>(&As[0][0]);     // [2][BM][LDH]
+        _Float16* Bh = reinterpret_cast<_Float16*>(&Bs[0][0]);     // [2][BN][LDH]
+        static_assert(LDH * 2 <= LDK * 4, "fp16 rows fit the fp32 tile buffers");
+        // staging set 0 = (ra, rb), set 1 = (ra1, rb1): the gathers of TWO k-tiles are in flight (the loop is bound by
+        // bytes in flight per CU, not by the 32-cycle MFMAs: measured 2x over one set on the ESRF layers)
+        auto store_tile16 = [&](int buf, auto SET) {
+          constexpr int set = decltype(SET)::value;
+#pragma unroll
+          for (int i = 0; i < AP; ++i) {
+            const f32x4 s = set ? ra1[i] : ra[i];
+            const f16x4 v = {(_Float16)s[0], (_Float16)s[1], (_Float16)s[2], (_Float16)s[3]};
+            *reinterpret_cast<f16x4*>(&Ah[(buf * BM + r0 + 32 * i) * LDH + c4 * 4]) = v;
+          }
+#pragma unroll
+          for (int j = 0; j < BP; ++j) {
+            const f32x4 s = set ? rb1[j] : rb[j];
+            const f16x4 v = {(_Float16)s[0], (_Float16)s[1], (_Float16)s[2], (_Float16)s[3]};
+            *reinterpret_cast<f16x4*>(&Bh[(buf * BN + r0 + 32 * j) * LDH + c4 * 4]) = v;
+          }
+        };
+        int q = qb;
+        int li = q / cpt, ch = q - li * cpt;
+        {
+          const Ctx c0 = tile_ctx(li, ch, true);
+#pragma unroll
+          for (int i = 0; i < AP; ++i) load_a(c0, i, Set0{});
+#pragma unroll
+          for (int j = 0; j < BP; ++j) load_b(c0, j, Set0{});
+          if (++ch == cpt) { ch = 0; ++li; }
+          const Ctx c1 = tile_ctx(li, ch, q + 1 < qe);
+#pragma unroll
+          for (int i = 0; i < AP; ++i) load_a(c1, i, Set1{});
+#pragma unroll
+          for (int j = 0; j < BP; ++j) load_b(c1, j, Set1{});
+        }
+        store_tile16(0, Set0{});
+        __syncthreads();
+        int buf = 0;
+        // one iteration: tile q is multiplied out of LDS[buf]; tile q+2 is fetched into set FETCH (free since the last
+        // iteration wrote it to LDS); tile q+1, fetched an iteration ago into the other set, goes to LDS[buf^1]
+        auto iteration16 = [&](auto FETCH, auto OTHER) {
+          if (++ch == cpt) { ch = 0; ++li; }
+          const Ctx cn = tile_ctx(li, ch, q + 2 < qe);       // past the end: every offset out of range, loads return 0
+#pragma unroll
+          for (int i = 0; i < AP; ++i) load_a(cn, i, FETCH);
+#pragma unroll
+          for (int j = 0; j < BP; ++j) load_b(cn, j, FETCH);
+          // lane l: row l&31, halves [16*step + 8*(l>>5), +8) of its row -- A[m][k] and W[n][k] alike
+          const _Float16* Ac = Ah + (buf * BM + wm * WM + lrow) * LDH + lh * 8;
+          const _Float16* Bc = Bh + (buf * BN + wn * WN + lrow) * LDH + lh * 8;
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            f16x8 ha[TM], hb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ha[i] = *reinterpret_cast<const f16x8*>(Ac + i * 32 * LDH + st * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) hb[j] = *reinterpret_cast<const f16x8*>(Bc + j * 32 * LDH + st * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+          }
+          store_tile16(buf ^ 1, OTHER);
+          __syncthreads();
+          buf ^= 1;
+          ++q;
+        };
+        while (q < qe) {
+          iteration16(Set0{}, Set1{});      // tile q+2 -> set 0 (its tile q went to LDS before), tile q+1 sits in set 1
+          if (q >= qe) break;
+          iteration16(Set1{}, Set0{});
+        }
+      }
+    } else if (qb < qe) {
       // Software pipeline, two k-tiles deep: while tile q is multiplied out of LDS, tile q+1 (gathers issued one
       // iteration ago) is written to the other LDS buffer and the gathers of tile q+2 are issued.  A lone block on
       // a CU (small layers, split-K tails) has ~1.5 iterations to cover the memory latency instead of ~0.5.
@@ -698,10 +783,18 @@ struct TileCfg { int bm, bn; };
 // fp32 MFMA cannot overlap with VALU work of the same SIMD, and a lone wave per SIMD cannot hide its barrier / memory
 // waits: prefer the largest tile that still gives every CU two resident blocks (>= 512 blocks), measured best on the
 // MorphoMNIST layer shapes at bs=512 (scratch/mb3.py).
-static TileCfg pick_tile(long long M, int N) {
+static TileCfg pick_tile(long long M, int N, bool f16) {
   TileCfg best = {64, 64};
   if (N <= 32) { best.bm = 128; best.bn = 32; return best; }
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (long long)((N + bn - 1) / bn); };
+  if (f16) {
+    // the fp16 loop is bound by the bytes its blocks pull through L2 (a 32-cycle MFMA is 16x the fp32 rate; operands
+    // are still fp32 in memory): 128x128 tiles halve them per FLOP -- measured 149 -> 290 TF/s on the 1024 -> 2048
+    // layer of the ESRF stacks -- as soon as they still give every other CU a block
+    if (N > 64 && blocks(128, 128) >= kNumCU / 2) { best.bm = 128; best.bn = 128; return best; }
+    if (N > 64 && blocks(64, 128) >= kNumCU / 2) { best.bm = 64; best.bn = 128; return best; }
+    return best;
+  }
   // measured (scratch/mb3.py): 64x64 (4 resident blocks per CU) wins or ties up to a few thousand blocks;
   // larger tiles only pay through lower L2/HBM traffic once the grid is many waves deep
   if (blocks(64, 64) <= 16 * kNumCU || N <= 64) return best;
@@ -719,7 +812,7 @@ static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps) {
     if (d.ph[i].nr * d.ph[i].ns > max_taps) max_taps = d.ph[i].nr * d.ph[i].ns;
     if (d.ph[i].M >= (1 << 24)) { set_error("gconv: more than 2^24 rows in one phase"); return -1; }
   }
-  tc = pick_tile(Mtot, d.Cout);
+  tc = pick_tile(Mtot, d.Cout, d.f16 && vec && (d.Cin % BK) == 0);
   if (!vec && tc.bn == 128) tc.bn = 64;
   if (tuning().bm > 0 && tuning().bn > 0) { tc.bm = tuning().bm; tc.bn = tuning().bn; }
   int tiles = 0;
@@ -796,9 +889,11 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   d.ws = reinterpret_cast<float*>(ws_payload(ws));
   dim3 grid(tiles, ntile_n, S), block(256);
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
+  const bool f16 = d.f16 && uni;
 #define LAUNCH(BM_, BN_, WMM, WNN)                                                                    \
   do {                                                                                                  \
-    if (uni) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2>), grid, block, 0, stream, d);      \
+    if (f16) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2, true>), grid, block, 0, stream, d); \
+    else if (uni) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2>), grid, block, 0, stream, d); \
     else if (pow2) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 3>), grid, block, 0, stream, d);  \
     else if (vec) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 1>), grid, block, 0, stream, d); \
     else hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 0>), grid, block, 0, stream, d);          \
@@ -823,6 +918,7 @@ static bool geom_ok(const AliConvGeom* g) {
 static void fill_epilogue(GDesc& d, const AliEpilogue* ep) {
   if (ep) d.ep = *ep;
   else memset(&d.ep, 0, sizeof(d.ep));
+  d.f16 = d.ep.mfma_f16 != 0;
 }
 
 }  // namespace ali
@@ -887,10 +983,12 @@ static bool setup_bwd_data(const AliConvGeom* g, GDesc& d) {
   return true;
 }
 
-extern "C" int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t* tile_rows, int32_t* pixel_major) {
+extern "C" int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* tile_rows,
+                                   int32_t* pixel_major) {
   if (!geom_ok(g) || (which != 0 && which != 1)) return 0;
   GDesc d;
   memset(&d, 0, sizeof(d));
+  d.f16 = mfma_f16 != 0;
   bool vec;
   if (which == 0) { setup_fwd(g, d); vec = (g->C % 4) == 0; }
   else { if (!setup_bwd_data(g, d)) return 0; vec = (g->K % 4) == 0; }

@@ -88,6 +88,11 @@ typedef struct {
   const float* bn_invstd;
   const float* bn_mask_in;     /* mode 2, or NULL; row stride bn_mask_ld */
   const float* bn_mask_pre;    /* mode 2, or NULL; row stride bn_mask_ld */
+  /* Arithmetic of the contraction: 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); 1 = operands
+   * rounded to fp16 on their way into LDS, v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5,
+   * esrf_acoustic.py:134-260) where the layer takes the uniform-tap path (input channel stride % 32 == 0, more
+   * than 32 output channels); other layers keep fp32.  Tensors in HBM are fp32 either way. */
+  int32_t mfma_f16;
 } AliEpilogue;
 
 /* ---- implicit-GEMM convolutions (fp32 MFMA v_mfma_f32_32x32x2_f32) -------
@@ -105,10 +110,11 @@ typedef struct {
  *                      channel of dy (logical count Cd_log), t = r*S+s.     */
 size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which /*0 fwd,1 bwd_data,2 bwd_weight*/);
 /* Number of M-tiles (= bn_part slots) ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) will launch for this
- * geometry, and the tile height in *tile_rows; 0 for a bad geometry.  Rows are ordered (pixel, image) when
+ * geometry with AliEpilogue.mfma_f16 = mfma_f16, and the tile height in *tile_rows; 0 for a bad geometry.  Rows are ordered (pixel, image) when
  * *pixel_major != 0 (then bn_groups needs B/groups % tile_rows == 0), (image, pixel) otherwise (then it needs
  * B/groups * P*Q % tile_rows == 0). */
-int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t* tile_rows, int32_t* pixel_major);
+int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* tile_rows,
+                        int32_t* pixel_major);
 int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w_kxc, float* y,
                  const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
 int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w_cxk, float* dx,

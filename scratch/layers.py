@@ -8,6 +8,7 @@ from ali_hip import ops
 from ali_hip.step import AliStepper
 import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "mnist"
+prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
 dev = torch.device("cuda")
 torch.manual_seed(1)
 pm = importlib.import_module("image_scms.mnist" if wl == "mnist" else bench.SPECT[wl][3])
@@ -15,7 +16,7 @@ E, G, D = pm.Encoder(), pm.Generator(), pm.Discriminator()
 for m in (E, G, D):
     m.apply(pm.init_weights); m.to(dev).train()
 ops.set_workspace_bytes(2 << 30)
-st = AliStepper(E, G, D, capture=False, betas=(0.5, 0.999) if wl == "mnist" else (0.5, 0.9))
+st = AliStepper(E, G, D, capture=False, betas=(0.5, 0.999) if wl == "mnist" else (0.5, 0.9), precision=prec)
 b = bench.synth_batch(512, dev, 0) if wl == "mnist" else bench.synth_spect_batch(wl, bench.SPECT[wl][4], dev, 0)
 N = 2
 for _ in range(2): st.step(*b)

@@ -141,3 +141,40 @@ def test_train_on_stream_vs_oracle(capture):
         # two sign-like Adam steps (E+G) / four (D): elements whose gradient is at rounding level may differ by ~lr each
         assert (err > 0.1 * lr).double().mean().item() < 2e-2, (nm, (err > 0.1 * lr).double().mean().item())
         assert err.mean().item() <= 0.05 * lr, (nm, err.mean().item())
+
+
+@pytest.mark.parametrize("family,d,B", [("esrf", 8, 2), ("audio", 8, 4)])
+def test_fp16_mfma_stepper_iteration_vs_fp32_oracle(family, d, B):
+    """BASELINE config 5 (esrf_acoustic.py:134-260,333-379 on the fp16-MFMA path, ``AliStepper(precision="f16")``:
+    forward and data-gradient GEMMs contract fp16-rounded operands with fp32 accumulation, loss-scaled gradients, fp32
+    master weights / weight-gradient accumulation / Adam) against the fp32 CPU oracle: the three losses and the two
+    scores within the north_star's 1e-3, reconstructions G(E(x)) within 1e-3 relative, and the Adam step of every
+    parameter (sign-like: +-lr) equal except where the gradient is at fp16-rounding level."""
+    from ali_hip import ops
+    from ali_hip.step import AliStepper
+    (Eo, Go, Do), (E, G, D), images, c, z = paired_models(family, d=d, B=B)
+    for m in (Eo, Go, Do, E, G, D):
+        m.train()
+    oe, od = orc.build_optimizers(Eo, Go, Do, family)
+    with torch.no_grad():
+        rec_o = Go(Eo(images, c), c)
+    stepper = AliStepper(E, G, D, betas=(0.5, 0.9), precision="f16")
+    assert stepper.loss_scale == 1024.0
+    with torch.no_grad(), ops.precision("f16"):
+        rec_p = G(E(images.cuda(), to_dev(c)), to_dev(c)).cpu()
+    rel = ((rec_p - rec_o).norm() / rec_o.norm()).item()
+    assert 0 < rel <= 1e-3, f"G(E(x)) fp16 vs fp32 oracle: rel L2 {rel:.3e}"
+    before = {nm: copy.deepcopy(m.state_dict()) for nm, m in (("E", Eo), ("G", Go), ("D", Do))}
+    ro = orc.ali_step(Eo, Go, Do, oe, od, images, c, z)
+    rp = stepper.step(images.cuda(), to_dev(c), z.cuda())
+    for k in ("loss_eg", "loss_d_real", "loss_d_fake", "dg", "de"):
+        assert abs(rp[k].item() - ro[k]) <= 1e-3 * max(1.0, abs(ro[k])), (k, rp[k].item(), ro[k])
+    lr = 1e-4
+    for nm, mo, mp in (("E", Eo, E), ("G", Go, G), ("D", Do, D)):
+        so = mo.state_dict()
+        wo = torch.cat([(so[k] - before[nm][k]).reshape(-1).double() for k in so])
+        wp = torch.cat([(v.cpu() - before[nm][k]).reshape(-1).double() for k, v in mp.state_dict().items()])
+        err = (wp - wo).abs()
+        assert err.max().item() <= 2.2 * lr * (2 if nm == "D" else 1)
+        assert (err > 0.05 * lr).double().mean().item() < 2e-2, (nm, (err > 0.05 * lr).double().mean().item())
+        assert err.mean().item() <= 0.03 * lr, (nm, err.mean().item())

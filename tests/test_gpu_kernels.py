@@ -530,3 +530,56 @@ def test_batchnorm_reductions_fused_into_the_gemm_epilogues(B, C, H, K, R, strid
     close(dgam, bn2.weight.grad, what="dgamma")
     close(dbet, bn2.bias.grad, what="dbeta")
     close(nchw(gprev), y0.grad, what="gx")
+
+
+F16_CASES = [
+    # kind, B, C, H, K, R, stride, pad        5x5 stride-2 family of esrf_acoustic.py:144-199 (+ 1x1 tail, split-K, phases)
+    ("conv", 4, 64, 31, 128, 5, 2, 1), ("conv", 3, 128, 15, 256, 5, 2, 1), ("conv", 64, 512, 1, 512, 1, 1, 0),
+    ("conv", 2, 256, 7, 512, 5, 2, 1), ("convT", 3, 128, 8, 64, 5, 2, 2), ("convT", 2, 64, 16, 32, 5, 2, 2),
+    ("conv", 2, 32, 40, 64, 5, 2, 1),
+]
+
+
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", F16_CASES)
+def test_fp16_mfma_gemm_path(kind, B, C, H, K, R, stride, pad):
+    """AliEpilogue.mfma_f16 (BASELINE config 5): operands rounded to fp16 on their way into LDS, fp32 accumulation.
+    (i) On data that fp16 holds exactly (small integers / powers of two) the result must EQUAL the fp32 path's bit for
+    bit -- this pins the fragment layout of v_mfma_f32_32x32x16_f16; (ii) on random data it must sit within fp16
+    operand rounding (2^-11 per operand, accumulated over the contraction) of the fp32 result."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 31 + C + K)
+    for exact in (True, False):
+        if exact:
+            x = torch.randint(-4, 5, (B, C, H, H), generator=g).float()
+            w = torch.randint(-2, 3, (K, C, R, R) if kind == "conv" else (C, K, R, R), generator=g).float() / 8
+        else:
+            x = torch.randn(B, C, H, H, generator=g)
+            w = torch.randn((K, C, R, R) if kind == "conv" else (C, K, R, R), generator=g) / (C * R * R) ** 0.5
+        xh = nhwc(x).cuda()
+        if kind == "conv":
+            P = (H + 2 * pad - R) // stride + 1
+            geom = ops.geom(B, H, H, C, P, P, K, R, R, stride, pad)
+            wp = pack_conv_fwd(ops, w, C)
+            outs = []
+            for prec in ("f32", "f16"):
+                y = torch.empty(B, P, P, K, device="cuda")
+                with ops.precision(prec):
+                    ops.conv_fwd(geom, xh, wp, y, ops.epilogue())
+                outs.append(y)
+        else:   # ConvTranspose2d forward == data-gradient GEMM, 4 sub-pixel phases
+            Ho = (H - 1) * stride - 2 * pad + R + 1
+            geom = ops.geom(B, Ho, Ho, K, H, H, C, R, R, stride, pad)
+            wp = torch.empty(K, R * R, C, device="cuda")
+            ops.pack_weights(w.cuda().contiguous(), wp, K, R * R, C, C, R * R, 1, K * R * R)
+            outs = []
+            for prec in ("f32", "f16"):
+                y = torch.empty(B, Ho, Ho, K, device="cuda")
+                with ops.precision(prec):
+                    ops.conv_bwd_data(geom, xh, wp, y, ops.epilogue())
+                outs.append(y)
+        if exact:
+            assert torch.equal(outs[0], outs[1]), f"{kind}: fp16 path differs on exactly representable data"
+        else:
+            scale = outs[0].abs().max().item()
+            err = (outs[0] - outs[1]).abs().max().item()
+            assert 0 < err <= 4e-3 * scale, (err, scale)
