@@ -224,11 +224,12 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
     lib = _lib.load()
     ws = workspace(x.device)
     tab = wgrad_pixtab(g, x.device) if (g.C % 4 == 0 and g.K % 4 == 0) else None
+    f16 = int(_PRECISION["f16"])
 
     def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
                                            s_dc, s_gc, s_tap, _opt(db, "db"),
-                                           None if tab is None else c_void_p(tab.data_ptr()), c_void_p(ws.data_ptr()),
+                                           None if tab is None else c_void_p(tab.data_ptr()), f16, c_void_p(ws.data_ptr()),
                                            ws.numel(), _stream()), "ali_conv_bwd_weight")
     _launch("wgrad", *_geom_cost(g), go)
     return dst

@@ -208,7 +208,17 @@ __device__ __forceinline__ void w_divmod(int m, int dv, float rcp, int& q, int& 
   else if (r >= dv) { ++q; r -= dv; }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB>
+// F16 (needs TAB): the fp16-MFMA variant (BASELINE config 5).  Both operands are rounded to fp16 on their way into
+// LDS, where they keep the [pixel][channel] order they have in memory (8-byte stores); v_mfma_f32_32x32x16_f16 wants 8
+// consecutive PIXELS per lane for one channel, i.e. the transposed image, which ds_read_b64_tr_b16 delivers for free:
+// per 16-lane group it reads a 4-pixel x 16-channel block and hands lane i channel i of the 4 pixels (verified on the
+// hardware by scratch/ub/tr16.hip).  Row pitch = channels + 32 halves: the 4 pixel rows of a block start 16 banks apart
+// (pitch/4 = 16 or 48 mod 64), so a half-wave's 32 x 8 bytes cover all 64 banks once.  fp32 accumulation, fp32 slabs.
+using wf16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using wf16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef short ws4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsigned x_bytes, unsigned dy_bytes) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -312,7 +322,91 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (pix_begin < pix_end) {
+  if (F16 && TAB) {
+    if (pix_begin < pix_end) {
+      constexpr int PA = BM + 32, PB = BN + 32;                 // halves per pixel row
+      static_assert(PA * 2 <= LDA * 4 && PB * 2 <= LDB * 4, "fp16 rows fit the fp32 tile buffers");
+      _Float16* A16 = reinterpret_cast<_Float16*>(&As[0][0]);   // [2][32][PA]
+      _Float16* B16 = reinterpret_cast<_Float16*>(&Bs[0][0]);   // [2][32][PB]
+      f32x4 ra1[AP], rb1[BP];                                    // second staging set: two k-tiles of gathers in flight
+      auto cvt_store = [&](int buf, const f32x4* sa, const f32x4* sb) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          const wf16x4 v = {(_Float16)sa[i][0], (_Float16)sa[i][1], (_Float16)sa[i][2], (_Float16)sa[i][3]};
+          *reinterpret_cast<wf16x4*>(&A16[(buf * WBK2 + arow0 + i * AROWS) * PA + a4 * 4]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+          const wf16x4 v = {(_Float16)sb[j][0], (_Float16)sb[j][1], (_Float16)sb[j][2], (_Float16)sb[j][3]};
+          *reinterpret_cast<wf16x4*>(&B16[(buf * WBK2 + brow0 + j * BROWS) * PB + b4 * 4]) = v;
+          if (do_db) dbacc += sb[j];
+        }
+      };
+      auto fetch = [&](int pix0, f32x4* sa, f32x4* sb) {      // gathers of the tile at pix0 (te holds its table entries)
+#pragma unroll
+        for (int i = 0; i < AP; ++i) { load_a(pix0, i); sa[i] = ra[i]; }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) { load_b(pix0, j); sb[j] = rb[j]; }
+      };
+      // (load_a / load_b write ra / rb; set 1 copies them -- register renaming, no instruction survives)
+      f32x4 sa0[AP], sb0[BP];
+#pragma unroll
+      for (int i = 0; i < AP; ++i) load_te(pix_begin, i);
+      fetch(pix_begin, sa0, sb0);
+#pragma unroll
+      for (int i = 0; i < AP; ++i) load_te(pix_begin + WBK2, i);
+      fetch(pix_begin + WBK2, ra1, rb1);
+#pragma unroll
+      for (int i = 0; i < AP; ++i) load_te(pix_begin + 2 * WBK2, i);
+      cvt_store(0, sa0, sb0);
+      __syncthreads();
+      int buf = 0;
+      // transposed fragment reads: lane l = 16*grp + 4*q + p addresses pixel row q, channels 4p..4p+3 of its group's
+      // 16-channel block; it receives channel (l & 15) of the block's 4 pixels.  grp & 1 selects the 16-channel half
+      // of the 32-wide MFMA operand, grp >> 1 (= lane >> 5) the 8-pixel half of the 16-pixel k-step.
+      const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1, th = lane >> 5;
+      const int a_col = wm * WM + 16 * tg + 4 * tp, b_col = wn * WN + 16 * tg + 4 * tp;
+      auto frag = [&](const _Float16* img, int pitch, int col, int k0) -> wf16x8 {
+        const _Float16* p0 = img + (k0 + 8 * th + tq) * pitch + col;
+        const ws4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws4v*)p0);
+        const ws4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws4v*)(p0 + 4 * pitch));
+        const wf16x4 l4 = __builtin_bit_cast(wf16x4, lo), h4 = __builtin_bit_cast(wf16x4, hi);
+        return wf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+      };
+      auto iteration16 = [&](int pix0, f32x4* fa_, f32x4* fb_, const f32x4* oa, const f32x4* ob) {
+        // tile pix0 is multiplied out of LDS[buf]; tile pix0 + 2*WBK2 is fetched into (fa_, fb_); tile pix0 + WBK2,
+        // fetched an iteration ago into (oa, ob), goes to LDS[buf ^ 1]
+        fetch(pix0 + 2 * WBK2, fa_, fb_);
+#pragma unroll
+        for (int i = 0; i < AP; ++i) load_te(pix0 + 3 * WBK2, i);
+        const _Float16* Ai = A16 + buf * WBK2 * PA;
+        const _Float16* Bi = B16 + buf * WBK2 * PB;
+#pragma unroll
+        for (int ks = 0; ks < WBK2 / 16; ++ks) {
+          wf16x8 ha[TM], hb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) ha[i] = frag(Ai, PA, a_col + i * 32, ks * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) hb[j] = frag(Bi, PB, b_col + j * 32, ks * 16);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+        }
+        cvt_store(buf ^ 1, oa, ob);
+        __syncthreads();
+        buf ^= 1;
+      };
+      for (int pix0 = pix_begin; pix0 < pix_end;) {
+        iteration16(pix0, sa0, sb0, ra1, rb1);
+        pix0 += WBK2;
+        if (pix0 >= pix_end) break;
+        iteration16(pix0, ra1, rb1, sa0, sb0);
+        pix0 += WBK2;
+      }
+    }
+  } else if (pix_begin < pix_end) {
     if (TAB) {
 #pragma unroll
       for (int i = 0; i < AP; ++i) load_te(pix_begin, i);
@@ -542,7 +636,8 @@ using namespace ali;
 
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
                                    int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
-                                   const int32_t* pixtab, void* ws, size_t ws_bytes, ali_stream_t stream_) {
+                                   const int32_t* pixtab, int32_t mfma_f16, void* ws, size_t ws_bytes,
+                                   ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
     return ALI_ERR_BAD_ARG;
@@ -572,7 +667,8 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     // the grid depth comes from the split over pixels
     long long small_lim = d.npix >= 200000 ? 16 : 2 * kNumCU;
     if (tuning().wgrad_small >= 0) small_lim = tuning().wgrad_small;
-    if (g->K > 32 && b64 <= small_lim) { bm = 64; bn = 64; }
+    const bool f16_tiles = mfma_f16 && pixtab && g->K > 64 && d.Mtot >= 128;   // fp16 loop: bytes-bound, big tiles
+    if (g->K > 32 && b64 <= small_lim && !f16_tiles) { bm = 64; bn = 64; }
     else if (g->K > 64) { bm = 128; bn = 128; }
     else if (g->K > 32) { bm = 128; bn = 64; }
     else { bm = 128; bn = 32; }
@@ -608,9 +704,11 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     const unsigned xb = (unsigned)(x_elems * 4), yb = (unsigned)(dy_elems * 4);
     // the table packs positions as 16-bit fields: maps up to 8191 x 8191
     d.pixtab = (pixtab && g->H < 0x2000 && g->W < 0x2000 && g->pad < 0x2000) ? pixtab : nullptr;
+    const bool f16 = mfma_f16 && d.pixtab;
 #define FLAUNCH(BM_, BN_, WMM, WNN)                                                                               \
   do {                                                                                                            \
-    if (d.pixtab) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true>), grid, block, 0, stream, d, xb, yb);   \
+    if (f16) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true, true>), grid, block, 0, stream, d, xb, yb);  \
+    else if (d.pixtab) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true>), grid, block, 0, stream, d, xb, yb);   \
     else hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, false>), grid, block, 0, stream, d, xb, yb);   \
   } while (0)
     if (bm == 64) FLAUNCH(64, 64, 2, 2);

@@ -123,6 +123,7 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                         int32_t Cg_log, int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap,
                         float* db /* optional: db[dc] = sum over pixels of dy (Conv2d bias gradient) */,
                         const int32_t* pixtab /* optional: ali_wgrad_pixtab of the same geometry */,
+                        int32_t mfma_f16 /* as AliEpilogue.mfma_f16 (needs pixtab); accumulation and slabs stay fp32 */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
 /* Per-geometry table for ali_conv_bwd_weight: entry i (2 x int32) of output pixel i = (b,p,q) holds the byte offset of
  * x[b, p*stride, q*stride, 0] and the packed pair (p*stride, q*stride); the kernel adds its tap's (r-pad, s-pad).  With it the kernel's gather

@@ -583,3 +583,39 @@ def test_fp16_mfma_gemm_path(kind, B, C, H, K, R, stride, pad):
             scale = outs[0].abs().max().item()
             err = (outs[0] - outs[1]).abs().max().item()
             assert 0 < err <= 4e-3 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", F16_CASES + [("conv", 70, 64, 9, 96, 5, 2, 1)])
+def test_fp16_mfma_weight_gradient(kind, B, C, H, K, R, stride, pad):
+    """ali_conv_bwd_weight(mfma_f16 = 1): both operands rounded to fp16 on their way into LDS (kept [pixel][channel],
+    read back transposed by ds_read_b64_tr_b16), fp32 accumulation and slabs.  Bit-identical to the fp32 path on data
+    fp16 holds exactly and whose sums fp32 holds exactly; within operand rounding of it on random data."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 13 + C + K)
+    for exact in (True, False):
+        if kind == "conv":
+            P = (H + 2 * pad - R) // stride + 1
+            xs, ys = (B, H, H, C), (B, P, P, K)                 # gathered operand x, dense operand dy
+            geom = ops.geom(B, H, H, C, P, P, K, R, R, stride, pad)
+        else:   # ConvTranspose2d weight gradient: gathered = its output gradient, dense = its input
+            Ho = (H - 1) * stride - 2 * pad + R + 1
+            xs, ys = (B, Ho, Ho, K), (B, H, H, C)
+            geom = ops.geom(B, Ho, Ho, K, H, H, C, R, R, stride, pad)
+        if exact:
+            x = torch.randint(-3, 4, xs, generator=g).float().cuda()
+            dy = (torch.randint(-2, 3, ys, generator=g).float() / 4).cuda()
+        else:
+            x, dy = torch.randn(xs, generator=g).cuda(), torch.randn(ys, generator=g).cuda()
+        Cg, Cd = xs[3], ys[3]
+        outs = []
+        for prec in ("f32", "f16"):
+            dw = torch.empty(Cd, Cg, R, R, device="cuda")
+            with ops.precision(prec):
+                ops.conv_bwd_weight(geom, x, dy, dw, Cg, Cd, Cg * R * R, R * R, 1)
+            outs.append(dw)
+        if exact:
+            assert torch.equal(outs[0], outs[1]), f"{kind}: fp16 weight gradient differs on exactly representable data"
+        else:
+            scale = outs[0].abs().max().item()
+            err = (outs[0] - outs[1]).abs().max().item()
+            assert 0 < err <= 4e-3 * scale, (err, scale)
