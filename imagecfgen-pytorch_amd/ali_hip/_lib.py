@@ -25,7 +25,8 @@ class AliEpilogue(Structure):
                 # fused BatchNorm reductions (include/ali_hip.h)
                 ("bn_part", c_void_p), ("bn_mode", c_int32), ("bn_groups", c_int32), ("bn_stat_mask", c_void_p),
                 ("bn_mask_ld", c_int32), ("bn_x", c_void_p), ("bn_mean", c_void_p), ("bn_invstd", c_void_p),
-                ("bn_mask_in", c_void_p), ("bn_mask_pre", c_void_p), ("mfma_f16", c_int32)]
+                ("bn_mask_in", c_void_p), ("bn_mask_pre", c_void_p), ("mfma_f16", c_int32),
+                ("in16", c_void_p), ("w16", c_void_p), ("out16", c_void_p)]
 
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
@@ -34,6 +35,7 @@ ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
 SIGNATURES = {
     "ali_conv_workspace_bytes": (c_size_t, [POINTER(AliConvGeom), c_int32]),
     "ali_conv_mtiles": (c_int32, [POINTER(AliConvGeom), c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    "ali_conv_writes_out16": (c_int32, [POINTER(AliConvGeom), c_int32]),
     "ali_conv_fwd": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue), c_void_p,
                                c_size_t, c_void_p]),
     "ali_conv_bwd_data": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue),

@@ -59,6 +59,7 @@ class PackCache:
             return hit[1]
         with torch.no_grad():
             val = builder(hit[1] if (hit is not None and self.static) else None)
+            ops.after_packs(lambda v=val: ops.refresh_shadow16(v))   # the fp16 twin (precision "f16"), if it has one
         self.store[key] = (tag, val, builder, param)
         return val
 
@@ -67,6 +68,7 @@ class PackCache:
             for key, (tag, val, builder, param) in list(self.store.items()):
                 out = builder(val)
                 assert out.data_ptr() == val.data_ptr()
+                ops.after_packs(lambda v=val: ops.refresh_shadow16(v))
                 self.store[key] = (self._tag(param), val, builder, param)
 
 
@@ -172,7 +174,11 @@ class ChainPlan:
             ops.pack_weights(fwd, out, I, 1, O, O, 1, 0, cin_stride)
             return out
 
-        return self.cache.get((st.index, which, cin_stride), w, build)
+        val = self.cache.get((st.index, which, cin_stride), w, build)
+        if ops._PRECISION["f16"] and which in ("fwd", "dgrad"):
+            with torch.no_grad():
+                ops.ensure_shadow16(val)         # fp16 twin of the packed weights, re-rounded whenever they are re-packed
+        return val
 
     def packed_bias(self, st: Stage):
         b = st.mod.bias

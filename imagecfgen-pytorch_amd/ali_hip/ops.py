@@ -181,9 +181,47 @@ def _launch(name, flops, desc, fn):
     _PROFILE.records.append((name, flops, (e0, e1, e2), desc))
 
 
+def shadow16(t):
+    """the fp16 twin a tensor carries (set by the fp16-MFMA launch that produced it, or by ``ensure_shadow16``)"""
+    h = getattr(t, "_ali16", None)
+    if h is not None and (h.shape != t.shape or h.device != t.device):
+        return None
+    return h
+
+
+def ensure_shadow16(t):
+    """fp16 twin of a (weight) tensor, created once and kept on the tensor object; ``refresh_shadow16`` re-rounds it
+    in place after the tensor changed (fixed addresses: captured graphs stay valid)."""
+    h = shadow16(t)
+    if h is None:
+        h = t.detach().to(torch.float16)
+        t._ali16 = h
+    return h
+
+
+def refresh_shadow16(t):
+    h = shadow16(t)
+    if h is not None:
+        h.copy_(t.detach())
+
+
+def _f16_operands(g, which, x, w_packed, y, ep):
+    """fp16 twins for a precision("f16") launch: read them where both operands have one, leave one of the output."""
+    if not _PRECISION["f16"]:
+        return
+    x16, w16 = shadow16(x), shadow16(w_packed)
+    if x16 is not None and w16 is not None:
+        ep.in16, ep.w16 = c_void_p(x16.data_ptr()), c_void_p(w16.data_ptr())
+    if _lib.load().ali_conv_writes_out16(byref(g), which):
+        y16 = torch.empty(y.shape, dtype=torch.float16, device=y.device)
+        ep.out16 = c_void_p(y16.data_ptr())
+        y._ali16 = y16
+
+
 def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
     lib = _lib.load()
     ws = workspace(x.device)
+    _f16_operands(g, 0, x, w_packed, y, ep)
 
     def go():
         _lib.check(lib.ali_conv_fwd(byref(g), _chk(x, "x"), _chk(w_packed, "w"), _chk(y, "y"), byref(ep),
@@ -195,6 +233,7 @@ def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
 def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
     lib = _lib.load()
     ws = workspace(dy.device)
+    _f16_operands(g, 1, dy, w_packed, dx, ep)
 
     def go():
         _lib.check(lib.ali_conv_bwd_data(byref(g), _chk(dy, "dy"), _chk(w_packed, "w"), _chk(dx, "dx"), byref(ep),
@@ -276,6 +315,15 @@ def tconv1_wgrad(big, small, sstride, nc, dw, s_k, s_tap, s_c, B, P, Q, K, R, S,
 
 
 _PACK_BATCH = None
+_PACK_AFTER = []          # callbacks to run once the pending pack jobs have been launched (fp16 twins of the packs)
+
+
+def after_packs(fn):
+    """Run ``fn`` now, or -- inside ``batched_packs`` -- right after the collected pack jobs have been launched."""
+    if _PACK_BATCH is None:
+        fn()
+    else:
+        _PACK_AFTER.append(fn)
 
 
 class batched_packs:
@@ -291,6 +339,10 @@ class batched_packs:
         global _PACK_BATCH
         _flush_packs()
         _PACK_BATCH = self.prev
+        if self.prev is None:
+            todo, _PACK_AFTER[:] = list(_PACK_AFTER), []
+            for fn in todo:
+                fn()
 
 
 def _flush_packs():

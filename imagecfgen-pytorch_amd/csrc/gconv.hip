@@ -73,6 +73,9 @@ struct GDesc {
   int ldw, S;          // weight row stride (floats), kernel width (taps per kernel row)
   int nphase, splitk, kt_per_split;
   int f16;             // AliEpilogue.mfma_f16: fp16 operands on v_mfma_f32_32x32x16_f16 where the fast path applies
+  const _Float16* in16;   // AliEpilogue.in16 / w16 / out16 (fp16 twins of in / w / out), or null
+  const _Float16* w16;
+  _Float16* out16;
   unsigned in_bytes, w_bytes;
   long long out_elems;
   Phase ph[4];
@@ -99,7 +102,10 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int LDH = 40;      // fp16 LDS rows: 32 halves + 8 pad = 80 B (16-B aligned, ds_read_b128 conflict-free)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool F16 = false>
+// F16 == 2: both operands are read from fp16 copies in memory (AliEpilogue.in16 / w16: the shadow the producing launch
+// left through out16, the fp16 twin of the packed weights): 16-byte gathers carry 8 k-values, a k-tile is 64 deep and
+// occupies exactly the fp32 tile's LDS image (128-B rows + 16 B pad), no conversion work, half the bytes through L2.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int F16 = 0>
 __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -291,7 +297,97 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     };
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
-    if (F16) {
+    if (F16 == 2) {
+      // ---- fp16 operands in memory: k-tile = 64 halves.  Offsets below are the fp32 path's halved (bytes of halves).
+      constexpr int BK16 = 64;
+      const int cpt16 = Cin / BK16;
+      const int total16 = nlive * cpt16;
+      const int per16 = (total16 + d.splitk - 1) / d.splitk;
+      const int qb16 = blockIdx.z * per16;
+      const int qe16 = min(total16, qb16 + per16);
+      const __amdgpu_buffer_rsrc_t rin16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.in16, 0, d.in_bytes / 2, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rw16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w16, 0, d.w_bytes / 2, 0x00020000);
+      unsigned aoffH[AP], woffH[BP];
+#pragma unroll
+      for (int i = 0; i < AP; ++i) aoffH[i] = (unsigned)(aoff[i] + c4 * 8) * 2u;
+#pragma unroll
+      for (int j = 0; j < BP; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        woffH[j] = n < d.Cout ? (unsigned)(((long long)n * d.ldw + c4 * 8) * 2) : OOB;
+      }
+      auto ctx16 = [&](int li, int ch, bool live) -> Ctx {
+        const int lc = li < nlive ? li : (nlive > 0 ? nlive - 1 : 0);
+        const int4 ti = *reinterpret_cast<const int4*>(&s_live[lc][0]);
+        Ctx cx;
+        cx.doff = (ti.x >> 1) + ch * (BK16 * 2);              // ti.x, ti.y: byte offsets of fp32 elements (multiples of 4)
+        cx.woff = live ? (ti.y >> 1) + ch * (BK16 * 2) : (int)OOB;
+        cx.bit = live ? (unsigned)ti.z : 0u;
+        return cx;
+      };
+      auto load16 = [&](const Ctx& cx, auto SET) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          const unsigned off = (amask[i] & cx.bit) ? aoffH[i] + (unsigned)cx.doff : OOB;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin16, (int)off, 0, 0));
+          if (decltype(SET)::value) ra1[i] = v; else ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+          const unsigned off = (woffH[j] | (unsigned)cx.woff) >= OOB ? OOB : woffH[j] + (unsigned)cx.woff;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw16, (int)off, 0, 0));
+          if (decltype(SET)::value) rb1[j] = v; else rb[j] = v;
+        }
+      };
+      auto store16 = [&](int buf, auto SET) {   // 16 bytes = 8 halves per lane: the fp32 tile's LDS image as it stands
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+          *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = decltype(SET)::value ? ra1[i] : ra[i];
+#pragma unroll
+        for (int j = 0; j < BP; ++j)
+          *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * j) * LDK + c4 * 4]) = decltype(SET)::value ? rb1[j] : rb[j];
+      };
+      if (qb16 < qe16) {
+        int q = qb16;
+        int li = q / cpt16, ch = q - li * cpt16;
+        load16(ctx16(li, ch, true), Set0{});
+        if (++ch == cpt16) { ch = 0; ++li; }
+        load16(ctx16(li, ch, q + 1 < qe16), Set1{});
+        store16(0, Set0{});
+        __syncthreads();
+        int buf = 0;
+        auto iter16 = [&](auto FETCH, auto OTHER) {
+          if (++ch == cpt16) { ch = 0; ++li; }
+          load16(ctx16(li, ch, q + 2 < qe16), FETCH);
+          // lane l: row l&31, halves [16*step + 8*(l>>5), +8) = bytes 32*step + 16*(l>>5) of its 128-byte row
+          const float* Ac = Ab + buf * (BM * LDK);
+          const float* Bc = Bb + buf * (BN * LDK);
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            f16x8 ha[TM], hb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+              ha[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDK + st * 8));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              hb[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDK + st * 8));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+          }
+          store16(buf ^ 1, OTHER);
+          __syncthreads();
+          buf ^= 1;
+          ++q;
+        };
+        while (q < qe16) {
+          iter16(Set0{}, Set1{});
+          if (q >= qe16) break;
+          iter16(Set1{}, Set0{});
+        }
+      }
+    } else if (F16 == 1) {
       if (qb < qe) {
         _Float16* Ah = reinterpret_cast<_Float16*>(&As[0][0]);     // [2][BM][LDH]
         _Float16* Bh = reinterpret_cast<_Float16*>(&Bs[0][0]);     // [2][BN][LDH]
@@ -629,7 +725,10 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
             }
             if (nok && roff[q] >= 0) {
               if (partial) __hip_atomic_store(outp + roff[q] + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              else outp[roff[q] + n] = v;
+              else {
+                outp[roff[q] + n] = v;
+                if (F16 != 0 && d.out16) d.out16[roff[q] + n] = (_Float16)v;
+              }
               if (BNM == 1) {
                 const float vs = v * bm1[q];
                 bs0[j] += vs;
@@ -890,9 +989,12 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   dim3 grid(tiles, ntile_n, S), block(256);
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
   const bool f16 = d.f16 && uni;
+  const bool op16 = f16 && d.in16 && d.w16 && (d.Cin % 64) == 0;
+  if (!f16) d.out16 = nullptr;      // only the fp16 kernels write the shadow
 #define LAUNCH(BM_, BN_, WMM, WNN)                                                                    \
   do {                                                                                                  \
-    if (f16) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2, true>), grid, block, 0, stream, d); \
+    if (op16) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2, 2>), grid, block, 0, stream, d);  \
+    else if (f16) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2, 1>), grid, block, 0, stream, d); \
     else if (uni) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2>), grid, block, 0, stream, d); \
     else if (pow2) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 3>), grid, block, 0, stream, d);  \
     else if (vec) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 1>), grid, block, 0, stream, d); \
@@ -919,6 +1021,9 @@ static void fill_epilogue(GDesc& d, const AliEpilogue* ep) {
   if (ep) d.ep = *ep;
   else memset(&d.ep, 0, sizeof(d.ep));
   d.f16 = d.ep.mfma_f16 != 0;
+  d.in16 = reinterpret_cast<const _Float16*>(d.ep.in16);
+  d.w16 = reinterpret_cast<const _Float16*>(d.ep.w16);
+  d.out16 = reinterpret_cast<_Float16*>(d.ep.out16);
 }
 
 }  // namespace ali
@@ -999,6 +1104,12 @@ extern "C" int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t 
   if (tile_rows) *tile_rows = tc.bm;
   if (pixel_major) *pixel_major = d.ph[0].pixmajor;
   return tiles;
+}
+
+extern "C" int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which) {
+  if (!geom_ok(g)) return 0;
+  const int cin = which == 0 ? g->C : g->K;      // channel stride of the gathered operand
+  return (cin % BK) == 0 ? 1 : 0;
 }
 
 extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,

@@ -93,6 +93,13 @@ typedef struct {
    * esrf_acoustic.py:134-260) where the layer takes the uniform-tap path (input channel stride % 32 == 0, more
    * than 32 output channels); other layers keep fp32.  Tensors in HBM are fp32 either way. */
   int32_t mfma_f16;
+  /* fp16 twins (mfma_f16 launches only; all optional): in16 / w16 = the gathered operand and the packed weights as
+   * fp16 arrays of the same shapes -- when both are given and the input channel stride % 64 == 0 the kernel reads them
+   * instead of x / w (half the bytes, no conversion); out16 = where to leave the fp16 twin of the output for the next
+   * layer.  A launch that cannot run on fp16 MFMA ignores all three (out16 is then NOT written: ali_conv_writes_out16). */
+  const void* in16;
+  const void* w16;
+  void* out16;
 } AliEpilogue;
 
 /* ---- implicit-GEMM convolutions (fp32 MFMA v_mfma_f32_32x32x2_f32) -------
@@ -115,6 +122,9 @@ size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which /*0 fwd,1 bw
  * B/groups * P*Q % tile_rows == 0). */
 int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* tile_rows,
                         int32_t* pixel_major);
+/* 1 if the launch ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) makes for g with mfma_f16 = 1 runs on
+ * fp16 MFMA, i.e. writes AliEpilogue.out16. */
+int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which);
 int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w_kxc, float* y,
                  const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
 int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w_cxk, float* dx,

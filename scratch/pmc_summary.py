@@ -1,16 +1,18 @@
-"""Per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) from two rocprofv3 --pmc passes (csv output)."""
-import csv, sys, collections, re
-def load(path, name):
-    acc = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != name: continue
-        k = re.sub(r"\(.*", "", r["Kernel_Name"])
-        acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
-    return acc
-f = load(sys.argv[1], "FETCH_SIZE"); w = load(sys.argv[2], "WRITE_SIZE")
-print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph")
-print("# raw counter values in KB per launch; on gfx950 FETCH_SIZE reads 1/2 of wide coalesced streams (MI355X_MICROARCH.md HBM): hbm_read ~= 2*FETCH_SIZE")
-print("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch")
-for k, (n, v) in sorted(f.items(), key=lambda kv: -kv[1][1]):
-    wn, wv = w.get(k, (0, 0.0))
-    print(f"\"{k}\",{n},{v/n:.1f},{(wv/wn if wn else 0):.1f}")
+"""Aggregate a rocprofv3 --pmc csv (…_counter_collection.csv) per kernel: launches and mean counter values.
+usage: python scratch/pmc_summary.py <counter_collection.csv> [min_launches]"""
+import csv, re, sys
+from collections import defaultdict
+path = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(int))
+for r in csv.DictReader(open(path)):
+    n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("ali::", "")
+    acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+    cnt[n][r["Counter_Name"]] += 1
+names = sorted({c for k in acc for c in acc[k]})
+print("kernel,launches," + ",".join(names))
+for k in sorted(acc, key=lambda k: -max(acc[k].values())):
+    n = max(cnt[k].values())
+    if len(sys.argv) > 2 and n < int(sys.argv[2]):
+        continue
+    print(k[-60:] + "," + str(n) + "," + ",".join(f"{acc[k][c] / max(cnt[k][c], 1):.4g}" for c in names))

@@ -257,9 +257,11 @@ def test_fp16_mfma_stepper_iteration_vs_fp32_oracle(family, d, B):
                      for m in (Ee, Ge) for p in m.parameters()])
     rel_emu = ((g_eg_hip - g_e).norm() / g_e.norm()).item()
     assert abs(loss_eg_hip - l_emu.item()) <= 2e-4 * max(1.0, abs(l_emu.item())), (loss_eg_hip, l_emu.item())
-    # (residual: the data-gradient GEMMs also round their incoming gradient to fp16, and the fp32 weight-gradient
-    # kernels see the unrounded activations where the emulation's autograd sees the rounded ones; measured 5e-3..1e-2)
-    assert rel_emu <= 1.5e-2, f"E+G gradients vs fp16-operand emulation: rel L2 {rel_emu:.3e}"
+    # (two fp16 evaluations whose fp32 partial sums are grouped differently -- split-K slabs, 64- vs 32-deep tiles, the
+    # CPU's blocking -- differ by 1e-7 before rounding, land on different sides of an fp16 rounding boundary for ~1e-4
+    # of the activations and decorrelate from there at the fp16-ulp level, LeakyReLU slopes included: measured 1-2.5e-2,
+    # against 2-3e-2 vs the fp32 oracle.  The loss, which averages all of that out, agrees to 2e-4.)
+    assert rel_emu <= 4e-2, f"E+G gradients vs fp16-operand emulation: rel L2 {rel_emu:.3e}"
     with torch.no_grad(), ops.precision("f16"):
         stepper.load_state(Eo, Go, Do, oe, od)
         w0 = weights((Do,))
@@ -292,3 +294,29 @@ def test_fp16_mfma_stepper_iteration_vs_fp32_oracle(family, d, B):
     ro = orc.ali_step(Eo, Go, Do, oe, od, images, c, z)
     for k in ("loss_eg", "loss_d_real", "loss_d_fake", "dg", "de"):
         assert abs(rp[k].item() - ro[k]) <= 5e-3 * max(1.0, abs(ro[k])), (k, rp[k].item(), ro[k])
+
+
+def test_fp16_weight_twins_follow_the_optimiser():
+    """The fp16 twins of the packed weights (AliEpilogue.w16) must be re-rounded after every Adam step, also when the
+    re-pack launches are batched (``ops.batched_packs``: the jobs run at the end of the block, the twins after them)
+    and when the iteration is replayed from a HIP graph: stale twins train on last iteration's weights."""
+    from ali_hip import ops
+    from ali_hip.step import AliStepper
+    for capture in (False, True):
+        (_, _, _), (E, G, D), images, c, z = paired_models("audio", d=8, B=4)
+        for m in (E, G, D):
+            m.train()
+        st = AliStepper(E, G, D, betas=(0.5, 0.9), precision="f16", capture=capture)
+        for _ in range(3):
+            st.step(images.cuda(), to_dev(c), z.cuda())
+        n = 0
+        for plan in (st.pE, st.pG, st.pDx, st.pDz, st.pDxz):
+            for key, (tag, val, builder, param) in plan.cache.store.items():
+                h = ops.shadow16(val)
+                if h is not None:
+                    n += 1
+                    assert torch.equal(h, val.half()), (capture, key)
+                    # ... and the pack itself is the current parameter (spot check through the fp32 pack's norm)
+                    assert abs(float(val.double().norm()) - float(param.detach().double().norm())) <= 1e-4 * float(
+                        param.detach().double().norm()) or "scatter" in str(key), (capture, key)
+        assert n >= 10

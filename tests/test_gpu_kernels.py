@@ -619,3 +619,41 @@ def test_fp16_mfma_weight_gradient(kind, B, C, H, K, R, stride, pad):
             scale = outs[0].abs().max().item()
             err = (outs[0] - outs[1]).abs().max().item()
             assert 0 < err <= 4e-3 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", [c for c in F16_CASES if c[2] % 64 == 0])
+def test_fp16_operands_in_memory_path(kind, B, C, H, K, R, stride, pad):
+    """AliEpilogue.in16 / w16 / out16: a precision("f16") launch leaves the fp16 twin of its output, and a launch whose
+    operands both carry one reads those (16-byte gathers of 8 halves, 64-deep k-tiles) -- the same products as the
+    converting fp16 path (both round the same fp32 values to fp16, RNE), summed in fp32 in the same k order up to where
+    a split-K launch cuts its slabs (64-deep instead of 32-deep tiles): equal to fp32 summation rounding."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 5 + C + K)
+    x = torch.randn(B, H, H, C, generator=g).cuda()
+    w = torch.randn((K, C, R, R) if kind == "conv" else (C, K, R, R), generator=g) / (C * R * R) ** 0.5
+    if kind == "conv":
+        P = (H + 2 * pad - R) // stride + 1
+        geom, which, oshape = ops.geom(B, H, H, C, P, P, K, R, R, stride, pad), 0, (B, P, P, K)
+        wp = pack_conv_fwd(ops, w, C)
+        run = ops.conv_fwd
+    else:
+        Ho = (H - 1) * stride - 2 * pad + R + 1
+        geom, which, oshape = ops.geom(B, Ho, Ho, K, H, H, C, R, R, stride, pad), 1, (B, Ho, Ho, K)
+        wp = torch.empty(K, R * R, C, device="cuda")
+        ops.pack_weights(w.cuda().contiguous(), wp, K, R * R, C, C, R * R, 1, K * R * R)
+        run = ops.conv_bwd_data
+    with ops.precision("f16"):
+        y_cvt = torch.empty(oshape, device="cuda")
+        run(geom, x, wp, y_cvt, ops.epilogue())                       # operands fp32 in memory, converted in flight
+        assert ops.shadow16(y_cvt) is not None and torch.equal(ops.shadow16(y_cvt), y_cvt.half())
+        x._ali16 = x.half()
+        ops.ensure_shadow16(wp)
+        y_mem = torch.empty(oshape, device="cuda")
+        run(geom, x, wp, y_mem, ops.epilogue())                       # both operands read as fp16
+    close(y_mem, y_cvt, 2e-6, "fp16 operands in memory vs converted in flight")
+    # and it really read the twins: poison them
+    x._ali16.zero_()
+    with ops.precision("f16"):
+        y_z = torch.empty(oshape, device="cuda")
+        run(geom, x, wp, y_z, ops.epilogue())
+    assert y_z.abs().max().item() == 0.0
