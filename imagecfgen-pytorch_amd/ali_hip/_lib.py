@@ -41,12 +41,13 @@ SIGNATURES = {
     "ali_conv_bwd_data": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue),
                                     c_void_p, c_size_t, c_void_p]),
     "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
-                                      c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+                                      c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
     "ali_wgrad_pixtab": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p]),
     "ali_pack_weights": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
                                    c_void_p]),
-    "ali_pack_weights_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32),
-                                         POINTER(c_int64), c_void_p]),
+    "ali_pack_weights_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                         POINTER(c_int32), POINTER(c_int64), c_void_p]),
     "ali_act_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "ali_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ali_rowmask_mul": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -189,20 +189,41 @@ def shadow16(t):
     return h
 
 
+_TWIN_OF = {}          # data_ptr of a packed-weight tensor -> weakref of its fp16 twin (the pack kernel writes both)
+_TWIN_WRITTEN = set()  # data_ptrs whose twin the pending / last pack launch wrote: no separate re-rounding needed
+
+
 def ensure_shadow16(t):
     """fp16 twin of a (weight) tensor, created once and kept on the tensor object; ``refresh_shadow16`` re-rounds it
     in place after the tensor changed (fixed addresses: captured graphs stay valid)."""
+    import weakref
     h = shadow16(t)
     if h is None:
         h = t.detach().to(torch.float16)
         t._ali16 = h
+        if len(_TWIN_OF) > 4096:
+            for k in [k for k, r in _TWIN_OF.items() if r() is None]:
+                del _TWIN_OF[k]
+        _TWIN_OF[t.data_ptr()] = weakref.ref(h)
     return h
 
 
 def refresh_shadow16(t):
     h = shadow16(t)
-    if h is not None:
-        h.copy_(t.detach())
+    if h is None:
+        return
+    if t.data_ptr() in _TWIN_WRITTEN:          # the pack launch that rewrote t wrote the twin as well
+        _TWIN_WRITTEN.discard(t.data_ptr())
+        return
+    h.copy_(t.detach())
+
+
+def _twin_for_pack(dst):
+    r = _TWIN_OF.get(dst.data_ptr())
+    h = r() if r is not None else None
+    if h is not None and h.numel() == dst.numel() and h.device == dst.device:
+        return h
+    return None
 
 
 def _f16_operands(g, which, x, w_packed, y, ep):
@@ -264,11 +285,16 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
     ws = workspace(x.device)
     tab = wgrad_pixtab(g, x.device) if (g.C % 4 == 0 and g.K % 4 == 0) else None
     f16 = int(_PRECISION["f16"])
+    x16, dy16 = (shadow16(x), shadow16(dy)) if f16 else (None, None)
+    if x16 is None or dy16 is None:
+        x16 = dy16 = None
 
     def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
                                            s_dc, s_gc, s_tap, _opt(db, "db"),
-                                           None if tab is None else c_void_p(tab.data_ptr()), f16, c_void_p(ws.data_ptr()),
+                                           None if tab is None else c_void_p(tab.data_ptr()), f16,
+                                           None if x16 is None else c_void_p(x16.data_ptr()),
+                                           None if dy16 is None else c_void_p(dy16.data_ptr()), c_void_p(ws.data_ptr()),
                                            ws.numel(), _stream()), "ali_conv_bwd_weight")
     _launch("wgrad", *_geom_cost(g), go)
     return dst
@@ -345,32 +371,40 @@ class batched_packs:
                 fn()
 
 
-def _flush_packs():
-    jobs = _PACK_BATCH
-    if not jobs:
-        return
+def _launch_packs(jobs):
+    """jobs: (src, dst, N, T, C, Cpad, s_n, s_tap, s_c) tuples; one launch per 40 (include/ali_hip.h)."""
     lib = _lib.load()
     for lo in range(0, len(jobs), 40):
         part = jobs[lo:lo + 40]
         n = len(part)
+        twins = [_twin_for_pack(j[1]) for j in part]
         srcs = (c_void_p * n)(*[j[0].data_ptr() for j in part])
         dsts = (c_void_p * n)(*[j[1].data_ptr() for j in part])
+        d16 = (c_void_p * n)(*[None if h is None else h.data_ptr() for h in twins])
         dims = (ctypes.c_int32 * (4 * n))(*[v for j in part for v in j[2:6]])
         strides = (ctypes.c_int64 * (3 * n))(*[v for j in part for v in j[6:9]])
-        _lib.check(lib.ali_pack_weights_multi(n, srcs, dsts, dims, strides, _stream()), "ali_pack_weights_multi")
+        _lib.check(lib.ali_pack_weights_multi(n, srcs, dsts, d16, dims, strides, _stream()), "ali_pack_weights_multi")
+        for j, h in zip(part, twins):
+            if h is not None:
+                _TWIN_WRITTEN.add(j[1].data_ptr())
+
+
+def _flush_packs():
+    jobs = _PACK_BATCH
+    if not jobs:
+        return
+    _launch_packs(jobs)
     jobs.clear()
 
 
 def pack_weights(src, dst, N, T, C, Cpad, s_n, s_tap, s_c):
+    _chk(src, "src"), _chk(dst, "dst")
     if _PACK_BATCH is not None:
-        _chk(src, "src"), _chk(dst, "dst")
         if any(j[1].data_ptr() == src.data_ptr() for j in _PACK_BATCH):
             _flush_packs()
         _PACK_BATCH.append((src, dst, N, T, C, Cpad, s_n, s_tap, s_c))
         return dst
-    lib = _lib.load()
-    _lib.check(lib.ali_pack_weights(_chk(src, "src"), _chk(dst, "dst"), N, T, C, Cpad, s_n, s_tap, s_c, _stream()),
-               "ali_pack_weights")
+    _launch_packs([(src, dst, N, T, C, Cpad, s_n, s_tap, s_c)])
     return dst
 
 

@@ -32,12 +32,63 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
 }
 
 // several re-layout jobs in one launch (the weight packs refreshed after an Adam step)
-struct PackJob { const float* src; float* dst; int N, T, C, Cpad; long long s_n, s_tap, s_c; int blk0; };
+// Every re-layout of the path is, per batch entry b, a 2-D transpose in[b][i][j] -> out[b][j][i] with the out rows
+// zero-padded from I to Ipad columns (Conv2d forward pack: b = n, i = c, j = tap; its data-gradient pack and the
+// ConvTranspose2d forward pack: one batch, i = the channel that ends up contiguous, j = (other channel, tap)).  Such
+// jobs go through 32 x 32 LDS tiles: 128-byte runs on both sides (the element-wise form reads with a stride of `taps`
+// floats: 0.6 TB/s on the 1.3 GB of ESRF weights).  `dst16`: optional fp16 twin of dst, written alongside.
+struct PackJob {
+  const float* src; float* dst; _Float16* dst16;
+  int N, T, C, Cpad; long long s_n, s_tap, s_c;
+  int blk0;
+  int tiled;                       // 1: batched transpose below
+  int batch, I, J, Ipad, ti, tj;   // tiles per batch entry: ti x tj
+  long long in_b, in_i, out_b;     // in[b*in_b + i*in_i + j], out[b*out_b + j*Ipad + i]
+};
 struct PackJobs { PackJob j[40]; int n; };
-__global__ void pack_weights_multi_kernel(PackJobs jobs) {
+__global__ void __launch_bounds__(256) pack_weights_multi_kernel(PackJobs jobs) {
+  __shared__ float tile[32][33];
   int k = 0;
   while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].blk0) ++k;
   const PackJob& J = jobs.j[k];
+  if (J.tiled) {
+    int rel = (int)blockIdx.x - J.blk0;
+    const int per = J.ti * J.tj;
+    const int b = rel / per;
+    rel -= b * per;
+    const int it = rel / J.tj, jt = rel - it * J.tj;
+    const int i0 = it * 32, j0 = jt * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    const float* in = J.src + (long long)b * J.in_b;
+    if (J.in_i == J.J && J.tj == 1) {
+      // few columns (taps) and rows back to back in memory: the tile's rows are ONE contiguous run of rows*J floats
+      const int rows = min(32, J.I - i0), n = rows > 0 ? rows * J.J : 0;
+      for (int r = ty; r < 32; r += 8) tile[r][tx] = 0.f;
+      __syncthreads();
+      const float* run = in + (long long)i0 * J.J;
+      for (int f = threadIdx.x; f < n; f += 256) {
+        const int r = f / J.J;
+        tile[r][f - r * J.J] = run[f];
+      }
+    } else {
+      for (int r = ty; r < 32; r += 8) {                                 // rows i, columns j (contiguous in src)
+        const int i = i0 + r, j = j0 + tx;
+        tile[r][tx] = (i < J.I && j < J.J) ? in[(long long)i * J.in_i + j] : 0.f;
+      }
+    }
+    __syncthreads();
+    float* out = J.dst + (long long)b * J.out_b;
+    _Float16* out16 = J.dst16 ? J.dst16 + (long long)b * J.out_b : nullptr;
+    for (int r = ty; r < 32; r += 8) {                                   // rows j, columns i (contiguous in dst)
+      const int j = j0 + r, i = i0 + tx;
+      if (j < J.J && i < J.Ipad) {
+        const float v = tile[tx][r];                                     // zero where i >= I (padding channels)
+        out[(long long)j * J.Ipad + i] = v;
+        if (out16) out16[(long long)j * J.Ipad + i] = (_Float16)v;
+      }
+    }
+    return;
+  }
   const int nblk = (k + 1 < jobs.n ? jobs.j[k + 1].blk0 : (int)gridDim.x) - J.blk0;
   const long long total = (long long)J.N * J.T * J.Cpad;
   long long i = (long long)((int)blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
@@ -47,7 +98,9 @@ __global__ void pack_weights_multi_kernel(PackJobs jobs) {
     const long long nt = i / J.Cpad;
     const int tp = (int)(nt % J.T);
     const long long n = nt / J.T;
-    J.dst[i] = c < J.C ? J.src[n * J.s_n + tp * J.s_tap + c * J.s_c] : 0.f;
+    const float v = c < J.C ? J.src[n * J.s_n + tp * J.s_tap + c * J.s_c] : 0.f;
+    J.dst[i] = v;
+    if (J.dst16) J.dst16[i] = (_Float16)v;
   }
 }
 
@@ -806,25 +859,47 @@ extern "C" int ali_pack_weights(const float* src, float* dst, int32_t N, int32_t
   return check_launch("pack_weights_kernel");
 }
 
-extern "C" int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, float* const* dst, const int32_t* dims,
-                                      const int64_t* strides, ali_stream_t stream) {
+extern "C" int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, float* const* dst, void* const* dst16,
+                                      const int32_t* dims, const int64_t* strides, ali_stream_t stream) {
   if (n_jobs < 1 || n_jobs > 40 || !src || !dst || !dims || !strides) { set_error("ali_pack_weights_multi: bad argument"); return ALI_ERR_BAD_ARG; }
   PackJobs jobs;
-  int blk = 0;
+  memset(&jobs, 0, sizeof(jobs));
+  long long blk = 0;
   for (int i = 0; i < n_jobs; ++i) {
     PackJob& J = jobs.j[i];
     J.src = src[i]; J.dst = dst[i];
+    J.dst16 = dst16 ? reinterpret_cast<_Float16*>(dst16[i]) : nullptr;
     J.N = dims[4 * i]; J.T = dims[4 * i + 1]; J.C = dims[4 * i + 2]; J.Cpad = dims[4 * i + 3];
     J.s_n = strides[3 * i]; J.s_tap = strides[3 * i + 1]; J.s_c = strides[3 * i + 2];
     if (!J.src || !J.dst || J.N <= 0 || J.T <= 0 || J.C <= 0 || J.Cpad < J.C) { set_error("ali_pack_weights_multi: bad job %d", i); return ALI_ERR_BAD_ARG; }
-    J.blk0 = blk;
-    long long nb = ((long long)J.N * J.T * J.Cpad + kEwBlock * 4 - 1) / (kEwBlock * 4);
-    if (nb > 256) nb = 256;
-    if (nb < 1) nb = 1;
-    blk += (int)nb;
+    J.blk0 = (int)blk;
+    // dst[(n*T + t)*Cpad + c] = src[n*s_n + t*s_tap + c*s_c] as a batched transpose in[b][i = c][j] -> out[b][j][i]:
+    //   src [N][C][T] (s_c = T, s_tap = 1, s_n = C*T): b = n, j = t                  (Conv2d forward pack, ...)
+    //   src [C][N][T] (s_n = T, s_tap = 1, s_c = N*T): one batch, j = n*T + t        (data-gradient packs, ...)
+    const long long NT = (long long)J.N * J.T;
+    // ... for the big ones only: a 32 x 32 tile per block costs more in block turnover than the strided reads cost
+    // while the source still sits in L2 / Infinity Cache (MorphoMNIST: 48 vs 107 us per launch; ESRF: 4.2 vs 1.1 ms)
+    const bool big = NT * J.Cpad >= (8LL << 20);
+    if (!big) {
+    } else if (J.s_tap == 1 && J.s_c == J.T && J.s_n == (long long)J.C * J.T && (long long)J.C * J.T >= 64) {
+      J.tiled = 1; J.batch = J.N; J.I = J.C; J.J = J.T; J.in_b = J.s_n; J.in_i = J.T; J.out_b = (long long)J.T * J.Cpad;
+    } else if (J.T >= 1 && J.s_tap == 1 && J.s_n == J.T && J.s_c == NT && NT < (1LL << 31) && NT >= 64) {
+      J.tiled = 1; J.batch = 1; J.I = J.C; J.J = (int)NT; J.in_b = 0; J.in_i = NT; J.out_b = 0;
+    }
+    if (J.tiled) {
+      J.Ipad = J.Cpad;
+      J.ti = (J.Ipad + 31) / 32; J.tj = (J.J + 31) / 32;
+      blk += (long long)J.batch * J.ti * J.tj;
+    } else {
+      long long nb = ((long long)J.N * J.T * J.Cpad + kEwBlock * 4 - 1) / (kEwBlock * 4);
+      if (nb > 256) nb = 256;
+      if (nb < 1) nb = 1;
+      blk += nb;
+    }
+    if (blk >= (1LL << 31)) { set_error("ali_pack_weights_multi: too many tiles"); return ALI_ERR_BAD_ARG; }
   }
   jobs.n = n_jobs;
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(blk), dim3(kEwBlock), 0, ST(stream), jobs);
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)blk), dim3(kEwBlock), 0, ST(stream), jobs);
   return check_launch("pack_weights_multi_kernel");
 }
 

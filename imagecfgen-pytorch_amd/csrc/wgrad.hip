@@ -33,6 +33,8 @@ struct WDesc {
   float* db;          // optional: db[dc] = sum_pix dy[pix][dc] (bias gradient), fused into the m-tile-0 blocks
   float* dbws;        // [splitk][Cd] slabs when splitk > 1
   const int* pixtab;  // optional [npix][2] (ali_wgrad_pixtab)
+  const _Float16* x16;   // fp16 twins of x / dy (same shapes), or null: the F16 == 2 kernels read these
+  const _Float16* dy16;
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VECA, bool VECB>
@@ -218,7 +220,9 @@ using wf16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using wf16x8 = __attribute__((ext_vector_type(8))) _Float16;
 typedef short ws4v __attribute__((__vector_size__(4 * sizeof(short))));
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB, bool F16 = false>
+// F16 == 2: both operands come from their fp16 twins in memory (WDesc.x16 / dy16, left by the fp16 launches that produced
+// the tensors): a 16-byte gather carries 8 channels, no conversion work, half the bytes.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB, int F16 = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsigned x_bytes, unsigned dy_bytes) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -322,7 +326,132 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (F16 && TAB) {
+  if constexpr (F16 == 2 && TAB) {
+    if (pix_begin < pix_end) {
+      constexpr int PA = BM + 32, PB = BN + 32;                 // halves per pixel row (see the F16 == 1 loop below)
+      constexpr int A8 = BM / 8, B8 = BN / 8;                   // 16-byte gathers per pixel row
+      constexpr int AROWS8 = 256 / A8, BROWS8 = 256 / B8;
+      constexpr int AP8 = WBK2 / AROWS8, BP8 = WBK2 / BROWS8;
+      static_assert(AP8 >= 1 && BP8 >= 1, "fp16-in-memory wgrad needs tiles of at least 64 x 64");
+      _Float16* A16 = reinterpret_cast<_Float16*>(&As[0][0]);   // [2][32][PA]
+      _Float16* B16 = reinterpret_cast<_Float16*>(&Bs[0][0]);   // [2][32][PB]
+      const __amdgpu_buffer_rsrc_t rx16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.x16, 0, x_bytes / 2, 0x00020000);
+      const __amdgpu_buffer_rsrc_t ry16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.dy16, 0, dy_bytes / 2, 0x00020000);
+      const int a8 = t % A8, arow8 = t / A8;
+      const int mA8 = m0 + a8 * 8;                              // 8 consecutive gathered channels of one tap (8 | Cg)
+      const bool a_ok8 = mA8 < d.Mtot;
+      const int tapA8 = a_ok8 ? mA8 / d.Cg : 0;
+      const int gcA8 = mA8 - tapA8 * d.Cg;
+      const int dhA8 = tapA8 / d.S - d.pad, dwA8 = tapA8 % d.S - d.pad;
+      const int tapoffA8 = ((dhA8 * d.W + dwA8) * d.Cg + gcA8) * 2;
+      const int b8 = t % B8, brow8 = t / B8;
+      const int nB8 = n0 + b8 * 8;
+      const bool b_ok8 = nB8 < d.Cd;
+      i32x2 te8[AP8];
+      auto load_te8 = [&](int pix0, int i) {
+        const int pix = pix0 + arow8 + i * AROWS8;
+        te8[i] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, pix * 8, 0, 0));
+      };
+      auto fetch8 = [&](int pix0, f32x4* sa, f32x4* sb) {
+#pragma unroll
+        for (int i = 0; i < AP8; ++i) {
+          unsigned off = OOB;
+          const int ih = (te8[i].y & 0xffff) - 0x4000 + dhA8, iw = (int)((unsigned)te8[i].y >> 16) - 0x4000 + dwA8;
+          if (a_ok8 && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) off = (unsigned)((te8[i].x >> 1) + tapoffA8);
+          sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx16, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < BP8; ++j) {
+          const int pix = pix0 + brow8 + j * BROWS8;
+          const unsigned off = (b_ok8 && pix < pix_end) ? (unsigned)(pix * d.Cd + nB8) * 2u : OOB;
+          sb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry16, (int)off, 0, 0));
+        }
+      };
+      f32x4 dbacc8 = {0.f, 0.f, 0.f, 0.f}, dbacc8b = {0.f, 0.f, 0.f, 0.f};   // bias gradient: channels nB8..+3, +4..+7
+      auto store8 = [&](int buf, const f32x4* sa, const f32x4* sb) {
+#pragma unroll
+        for (int i = 0; i < AP8; ++i)
+          *reinterpret_cast<f32x4*>(&A16[(buf * WBK2 + arow8 + i * AROWS8) * PA + a8 * 8]) = sa[i];
+#pragma unroll
+        for (int j = 0; j < BP8; ++j) {
+          *reinterpret_cast<f32x4*>(&B16[(buf * WBK2 + brow8 + j * BROWS8) * PB + b8 * 8]) = sb[j];
+          if (do_db) {
+            const wf16x8 h = __builtin_bit_cast(wf16x8, sb[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dbacc8[e] += (float)h[e]; dbacc8b[e] += (float)h[4 + e]; }
+          }
+        }
+      };
+      f32x4 sa0[AP8], sb0[BP8], sa1[AP8], sb1[BP8];
+#pragma unroll
+      for (int i = 0; i < AP8; ++i) load_te8(pix_begin, i);
+      fetch8(pix_begin, sa0, sb0);
+#pragma unroll
+      for (int i = 0; i < AP8; ++i) load_te8(pix_begin + WBK2, i);
+      fetch8(pix_begin + WBK2, sa1, sb1);
+#pragma unroll
+      for (int i = 0; i < AP8; ++i) load_te8(pix_begin + 2 * WBK2, i);
+      store8(0, sa0, sb0);
+      __syncthreads();
+      int buf = 0;
+      const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1, th = lane >> 5;
+      const int a_col = wm * WM + 16 * tg + 4 * tp, b_col = wn * WN + 16 * tg + 4 * tp;
+      auto frag = [&](const _Float16* img, int pitch, int col, int k0) -> wf16x8 {
+        const _Float16* p0 = img + (k0 + 8 * th + tq) * pitch + col;
+        const ws4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws4v*)p0);
+        const ws4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws4v*)(p0 + 4 * pitch));
+        const wf16x4 l4 = __builtin_bit_cast(wf16x4, lo), h4 = __builtin_bit_cast(wf16x4, hi);
+        return wf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+      };
+      auto iter8 = [&](int pix0, f32x4* fa_, f32x4* fb_, const f32x4* oa, const f32x4* ob) {
+        fetch8(pix0 + 2 * WBK2, fa_, fb_);
+#pragma unroll
+        for (int i = 0; i < AP8; ++i) load_te8(pix0 + 3 * WBK2, i);
+        const _Float16* Ai = A16 + buf * WBK2 * PA;
+        const _Float16* Bi = B16 + buf * WBK2 * PB;
+#pragma unroll
+        for (int ks = 0; ks < WBK2 / 16; ++ks) {
+          wf16x8 ha[TM], hb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) ha[i] = frag(Ai, PA, a_col + i * 32, ks * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) hb[j] = frag(Bi, PB, b_col + j * 32, ks * 16);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+        }
+        store8(buf ^ 1, oa, ob);
+        __syncthreads();
+        buf ^= 1;
+      };
+      for (int pix0 = pix_begin; pix0 < pix_end;) {
+        iter8(pix0, sa0, sb0, sa1, sb1);
+        pix0 += WBK2;
+        if (pix0 >= pix_end) break;
+        iter8(pix0, sa1, sb1, sa0, sb0);
+        pix0 += WBK2;
+      }
+      if (do_db) {   // column sums of this thread's 8 channels over its pixel rows -> the fp32 path's fold layout
+        __syncthreads();
+        float* red = &As[0][0];                     // [BROWS8][BN] floats <= tile size
+        *reinterpret_cast<f32x4*>(&red[brow8 * BN + b8 * 8]) = dbacc8;
+        *reinterpret_cast<f32x4*>(&red[brow8 * BN + b8 * 8 + 4]) = dbacc8b;
+        __syncthreads();
+        if (t < BN) {
+          float sum = 0.f;
+          for (int r = 0; r < BROWS8; ++r) sum += red[r * BN + t];
+          const int n = n0 + t;
+          if (n < d.Cd_log) {
+            if (d.splitk > 1) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
+            else d.db[n] = sum;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  } else if constexpr (F16 == 1 && TAB) {
     if (pix_begin < pix_end) {
       constexpr int PA = BM + 32, PB = BN + 32;                 // halves per pixel row
       static_assert(PA * 2 <= LDA * 4 && PB * 2 <= LDB * 4, "fp16 rows fit the fp32 tile buffers");
@@ -489,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   }
 
   const bool partial = d.splitk > 1;
-  if (do_db) {   // fold the per-thread column sums over the BROWS row lanes (fixed order), then one store per column
+  if (do_db && F16 != 2) {   // fold the per-thread column sums over the BROWS row lanes (fixed order), then one store per column
     __syncthreads();
     float* red = &As[0][0];                       // BROWS x BN floats <= tile size
     *reinterpret_cast<f32x4*>(&red[brow0 * BN + b4 * 4]) = dbacc;
@@ -636,8 +765,8 @@ using namespace ali;
 
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
                                    int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
-                                   const int32_t* pixtab, int32_t mfma_f16, void* ws, size_t ws_bytes,
-                                   ali_stream_t stream_) {
+                                   const int32_t* pixtab, int32_t mfma_f16, const void* x16, const void* dy16,
+                                   void* ws, size_t ws_bytes, ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
     return ALI_ERR_BAD_ARG;
@@ -705,17 +834,26 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     // the table packs positions as 16-bit fields: maps up to 8191 x 8191
     d.pixtab = (pixtab && g->H < 0x2000 && g->W < 0x2000 && g->pad < 0x2000) ? pixtab : nullptr;
     const bool f16 = mfma_f16 && d.pixtab;
-#define FLAUNCH(BM_, BN_, WMM, WNN)                                                                               \
+    const bool mem16 = f16 && x16 && dy16 && (g->C % 8) == 0 && (g->K % 8) == 0 && bn >= 64;
+    d.x16 = mem16 ? reinterpret_cast<const _Float16*>(x16) : nullptr;
+    d.dy16 = mem16 ? reinterpret_cast<const _Float16*>(dy16) : nullptr;
+#define FLAUNCH1(BM_, BN_, WMM, WNN)                                                                              \
   do {                                                                                                            \
-    if (f16) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true, true>), grid, block, 0, stream, d, xb, yb);  \
+    if (f16) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true, 1>), grid, block, 0, stream, d, xb, yb);     \
     else if (d.pixtab) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true>), grid, block, 0, stream, d, xb, yb);   \
     else hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, false>), grid, block, 0, stream, d, xb, yb);   \
+  } while (0)
+#define FLAUNCH(BM_, BN_, WMM, WNN)                                                                               \
+  do {                                                                                                            \
+    if (mem16) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true, 2>), grid, block, 0, stream, d, xb, yb);   \
+    else FLAUNCH1(BM_, BN_, WMM, WNN);                                                                            \
   } while (0)
     if (bm == 64) FLAUNCH(64, 64, 2, 2);
     else if (bn == 128) FLAUNCH(128, 128, 2, 2);
     else if (bn == 64) FLAUNCH(128, 64, 2, 2);
-    else FLAUNCH(128, 32, 4, 1);
+    else FLAUNCH1(128, 32, 4, 1);
 #undef FLAUNCH
+#undef FLAUNCH1
   } else {
 #define WLAUNCH(BN_, WMM, WNN)                                                                        \
   do {                                                                                                 \

@@ -134,6 +134,8 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                         float* db /* optional: db[dc] = sum over pixels of dy (Conv2d bias gradient) */,
                         const int32_t* pixtab /* optional: ali_wgrad_pixtab of the same geometry */,
                         int32_t mfma_f16 /* as AliEpilogue.mfma_f16 (needs pixtab); accumulation and slabs stay fp32 */,
+                        const void* x16, const void* dy16 /* optional fp16 twins of x / dy (AliEpilogue.out16 of the
+                                                             launches that produced them): read instead of x / dy */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
 /* Per-geometry table for ali_conv_bwd_weight: entry i (2 x int32) of output pixel i = (b,p,q) holds the byte offset of
  * x[b, p*stride, q*stride, 0] and the packed pair (p*stride, q*stride); the kernel adds its tap's (r-pad, s-pad).  With it the kernel's gather
@@ -169,8 +171,9 @@ int ali_pack_weights(const float* src, float* dst, int32_t N, int32_t T, int32_t
 
 /* the same for up to 40 parameters in one launch (all packs of a parameter group after its Adam step):
  * dims[4*i..] = {N, T, C, Cpad}, strides[3*i..] = {s_n, s_tap, s_c} of job i (host arrays). */
-int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, float* const* dst, const int32_t* dims,
-                           const int64_t* strides, ali_stream_t stream);
+int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, float* const* dst,
+                           void* const* dst16 /* optional (array and entries): fp16 twin of dst[i], written alongside */,
+                           const int32_t* dims, const int64_t* strides, ali_stream_t stream);
 
 /* ---- pointwise / reduction kernels (HBM bound) --------------------------- */
 /* gpre = gy * act'(y)  (backward of nn.LeakyReLU / nn.Tanh, mnist.py:32-73) */

@@ -657,3 +657,61 @@ def test_fp16_operands_in_memory_path(kind, B, C, H, K, R, stride, pad):
         y_z = torch.empty(oshape, device="cuda")
         run(geom, x, wp, y_z, ops.epilogue())
     assert y_z.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", [c for c in F16_CASES if c[2] % 8 == 0 and c[4] >= 64])
+def test_fp16_weight_gradient_from_twins(kind, B, C, H, K, R, stride, pad):
+    """ali_conv_bwd_weight fed the fp16 twins of both operands (x16 / dy16): same products as the converting fp16 path
+    (the twins ARE the rounded operands), fp32 sums up to slab grouping; the fused Conv2d bias gradient is the column
+    sum of the twin.  Poisoned twins prove they are what is read."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 3 + C + K)
+    if kind == "conv":
+        P = (H + 2 * pad - R) // stride + 1
+        xs, ys = (B, H, H, C), (B, P, P, K)
+        geom = ops.geom(B, H, H, C, P, P, K, R, R, stride, pad)
+    else:
+        Ho = (H - 1) * stride - 2 * pad + R + 1
+        xs, ys = (B, Ho, Ho, K), (B, H, H, C)
+        geom = ops.geom(B, Ho, Ho, K, H, H, C, R, R, stride, pad)
+    x, dy = torch.randn(xs, generator=g).cuda(), torch.randn(ys, generator=g).cuda()
+    Cg, Cd = xs[3], ys[3]
+    outs, dbs = [], []
+    with ops.precision("f16"):
+        for twins in (False, True):
+            if twins:
+                x._ali16, dy._ali16 = x.half(), dy.half()
+            dw = torch.empty(Cd, Cg, R, R, device="cuda")
+            db = torch.empty(Cd, device="cuda")
+            ops.conv_bwd_weight(geom, x, dy, dw, Cg, Cd, Cg * R * R, R * R, 1, db=db)
+            outs.append(dw), dbs.append(db)
+        close(outs[1], outs[0], 2e-6, "weight gradient from twins vs converted in flight")
+        close(dbs[1], dy.half().float().sum(dim=(0, 1, 2)), 1e-5, "bias gradient from the twin")
+        close(dbs[0], dy.sum(dim=(0, 1, 2)), 1e-5, "bias gradient (fp32 operand)")
+        x._ali16.zero_()
+        dw = torch.empty(Cd, Cg, R, R, device="cuda")
+        ops.conv_bwd_weight(geom, x, dy, dw, Cg, Cd, Cg * R * R, R * R, 1)
+        assert dw.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("K,C,R,cpad", [(64, 5, 3, 8), (128, 64, 4, 64), (96, 771, 3, 800), (33, 40, 5, 40), (512, 512, 1, 512),
+                                         (1024, 512, 5, 512), (4100, 2052, 1, 2052)])   # the last two: tiled transposes
+def test_pack_weights_tiled_transposes_and_fp16_twin(K, C, R, cpad):
+    """ali_pack_weights_multi: the Conv2d forward pack [K][T][Cpad] and data-gradient pack [Cpad][T][K] (tiled LDS
+    transposes; element-wise fallback for the shapes that are not) vs torch permutes, zero padding channels included,
+    and the fp16 twin written by the same launch."""
+    ops = _ops()
+    w = torch.randn(K, C, R, R, generator=torch.Generator().manual_seed(K + C)).cuda()
+    T = R * R
+    fwd = torch.full((K, T, cpad), float("nan"), device="cuda")
+    ops.ensure_shadow16(fwd)
+    ops.pack_weights(w, fwd, K, T, C, cpad, C * T, 1, T)
+    ref = torch.zeros(K, T, cpad, device="cuda")
+    ref[:, :, :C] = w.permute(0, 2, 3, 1).reshape(K, T, C)
+    assert torch.equal(fwd, ref)
+    assert torch.equal(ops.shadow16(fwd), ref.half())
+    dg = torch.full((cpad, T, K), float("nan"), device="cuda")
+    with ops.batched_packs():
+        ops.pack_weights(w, dg, C, T, K, K, T, 1, C * T)
+    ref = w.permute(1, 2, 3, 0).reshape(C, T, K)
+    assert torch.equal(dg[:C], ref) and torch.isnan(dg[C:]).all()        # rows >= C belong to the caller (kept zero)
