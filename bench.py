@@ -23,7 +23,9 @@ BS_PER_GPU = 512
 ALG_BYTES_PER_IMG = 8108239.0
 ALG_FLOP_PER_IMG = 1.0026e9
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_CSV = "profiles/r02_pmc_hbm_traffic_bs512.csv"
 
 
 def synth_batch(bs, device, seed):
@@ -216,11 +218,13 @@ def main():
                 g0[k] += fam["gconv_t"][k]
             del fam["gconv_t"]
         def pmc_traffic(kernel_substr):
-            """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this workload
-            (profiles/r01_pmc_hbm_traffic_bs512.csv: FETCH_SIZE / WRITE_SIZE in KB per launch, separate passes; on
-            gfx950 FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md) -- None if not present."""
-            path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_bs512.csv")
-            if args.workload != "mnist" or not os.path.exists(path):
+            """HBM bytes per launch of a kernel family from the COMMITTED rocprofv3 PMC passes of this workload
+            (TRAFFIC_CSV: FETCH_SIZE / WRITE_SIZE in KB per launch, separate passes of the same command; on gfx950
+            FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md).  Counters cannot be read from inside
+            the timed process: the figure is a property of the kernels at the benched shapes, not of this run -- the
+            JSON says so in ``traffic_source``.  None if no pass covers this workload / precision."""
+            path = os.path.join(ROOT, TRAFFIC_CSV)
+            if args.workload != "mnist" or args.precision != "f32" or not os.path.exists(path):
                 return None
             n = tot = 0.0
             for line in open(path):
@@ -236,15 +240,24 @@ def main():
             name = max(fam, key=lambda k: fam[k]["ms"])
             f = fam[name]
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": {"gconv": "ali::gconv_kernel", "wgrad": "ali::wgrad_kernel"}[name],
-                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": pmc_traffic({"gconv": "gconv_kernel", "wgrad": "wgrad_fast_kernel"}[name]),
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
+            ksub = {"gconv": "gconv_kernel", "wgrad": "wgrad_fast_kernel"}
+
+            def pair(k):      # algorithmic bytes next to the counters' traffic, per launch, for one kernel family
+                v = fam[k]
+                return {"alg_bytes_per_launch": round(v["bytes"] / v["launches"]), "traffic": pmc_traffic(ksub[k])}
+
+            roof = {"bound": "mfma", "kernel": {"gconv": "ali::gconv_kernel", "wgrad": "ali::wgrad_fast_kernel"}[name],
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": pmc_traffic(ksub[name]),
+                    "traffic_source": TRAFFIC_CSV + " (committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command;"
+                                      " not measured in this run)" if pmc_traffic(ksub[name]) is not None else None,
                     "alg_bytes_per_launch": round(f["bytes"] / f["launches"]),
                     "alg_flop_per_launch": round(f["flops"] / f["launches"]),
                     "launches_per_step": f["launches"], "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2),
-                    "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fam.items()}}
+                    "families": {k: dict({"launches": v["launches"], "ms": round(v["ms"], 3),
+                                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)},
+                                         **(pair(k) if k in ksub else {})) for k, v in fam.items()}}
         names = {"mnist": "image_scms/mnist.py ALI iteration (EG step + 2 D steps + diagnostics), MorphoMNIST 28x28x1",
                  "audio": "image_scms/audio_mnist.py ALI iteration, AudioMNIST log-spectrogram 128x128x1",
                  "whale": "image_scms/whalecalls.py BiGAN iteration, whale-call spectrogram 256x256x1",
@@ -269,6 +282,8 @@ def main():
             out["step_roofline"] = None          # SURVEY 8(d) per-image figures of the other configs: see DESIGN.md
         if world == 1 and not args.no_cpu_baseline and args.workload == "mnist":
             out["cpu_baseline"] = cpu_baseline(bs)
+            if bs != 64:      # BASELINE.json configs[0]: the reference's own CPU-runnable case
+                out["cpu_baseline"]["config0_bs64"] = cpu_baseline(64, budget_s=8.0)
         else:
             out["cpu_baseline"] = None
     if world > 1:
