@@ -1040,6 +1040,121 @@ extern "C" size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which) 
   return kWsReserved + (size_t)64 * g->R * g->S * g->C * g->K * sizeof(float);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// First Conv2d of the MorphoMNIST Discriminator (mnist.py:108: 5 -> 32 channels, 5x5, stride 1, no padding, on the
+// 8-channel NHWC plane tensor): K = 200, N = 32.  In the implicit-GEMM kernel it is neither MFMA nor HBM bound (7
+// k-tiles per block: prologue + epilogue dominate, 65 TF/s; the layer moves 50 MB for 2.4 GFLOP).  Here ONE block owns
+// ONE image: the 28x28x8 image (25 KB) and the 32x200 weights are staged in LDS once, every wave keeps all 25 weight
+// fragments in registers and walks its share of the 18 32-pixel M-tiles: per tap one ds_read_b128 of the image and 4
+// MFMAs (a lane's 4 consecutive channels feed 4 k-steps; A and B use the same permutation).  Same arithmetic as the
+// GEMM kernel (fp32 MFMA, k ascending tap by tap), same epilogue semantics (bias, LeakyReLU, fused BatchNorm
+// statistics: one slot per image).
+constexpr int CF_C = 8, CF_K = 32;
+constexpr int CF_PIXLD = 12;   // LDS pixel stride (dwords): 12 mod 64 -> the image's ds_read_b128 are conflict-free
+constexpr int CF_WLD = 200;    // weight rows as packed (read once per wave: conflicts do not matter); 64,256 B of LDS in all
+
+struct CFDesc {
+  const float* in; const float* w; float* out;
+  AliEpilogue ep;
+  int B, H, W, P, Q, R, S;
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_first_kernel(const CFDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float cf_smem[];
+  float* img = cf_smem;                                   // [H*W][CF_PIXLD]
+  float* wl = cf_smem + d.H * d.W * CF_PIXLD;             // [32][CF_WLD]
+  float* red = wl + CF_K * CF_WLD;                        // [2][4][32] BatchNorm partials of the 4 waves
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x;
+  const int HW = d.H * d.W, PQ = d.P * d.Q;
+  const float* src = d.in + (long long)b * HW * CF_C;
+  for (int i = t; i < HW * 2; i += 256) {                 // 2 float4 per pixel
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
+    *reinterpret_cast<f32x4*>(img + (i >> 1) * CF_PIXLD + (i & 1) * 4) = v;
+  }
+  for (int i = t; i < CF_K * TAPS * 2; i += 256) {        // packed weights [32][TAPS][8]
+    const int n = i / (TAPS * 2), rem = i - n * (TAPS * 2);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(d.w + (long long)n * TAPS * CF_C + rem * 4);
+    *reinterpret_cast<f32x4*>(wl + n * CF_WLD + rem * 4) = v;
+  }
+  __syncthreads();
+  const int lrow = lane & 31, lh = lane >> 5;
+  f32x4 wf[TAPS];                                         // B fragments of every tap: row n = lane&31, channels 4*lh..+3
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) wf[tp] = *reinterpret_cast<const f32x4*>(wl + lrow * CF_WLD + tp * CF_C + lh * 4);
+  const AliEpilogue& ep = d.ep;
+  const float bias = ep.bias ? ep.bias[lrow] : 0.f;
+  const float smask = (ep.bn_part && ep.bn_stat_mask) ? ep.bn_stat_mask[(long long)b * ep.bn_mask_ld + lrow] : 1.f;
+  float bs0 = 0.f, bs1 = 0.f;
+  const int ntile = (PQ + 31) / 32;
+  float* outb = d.out + (long long)b * PQ * CF_K;
+  for (int mt = wave; mt < ntile; mt += 4) {
+    const int m = mt * 32 + lrow;
+    const int mc = m < PQ ? m : PQ - 1;                   // clamp: rows past the end compute garbage, never stored
+    const int p = mc / d.Q, q = mc - p * d.Q;
+    const float* a0 = img + (p * d.W + q) * CF_PIXLD + lh * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const int r = tp / d.S, sx = tp - r * d.S;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + (r * d.W + sx) * CF_PIXLD);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wf[tp][e], acc, 0, 0, 0);
+    }
+    // acc(row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < PQ) {
+        const float v = apply_act(acc[r] + bias, ep.act, ep.slope);
+        outb[(long long)row * CF_K + lrow] = v;
+        const float vs = v * smask;
+        bs0 += vs;
+        bs1 += vs * vs;
+      }
+    }
+  }
+  if (ep.bn_part) {                                       // bn_mode 1: slot = image (passes of a batched launch: contiguous)
+    bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 32, 64);
+    if (lane < 32) { red[(0 * 4 + wave) * 32 + lane] = bs0; red[(1 * 4 + wave) * 32 + lane] = bs1; }
+    __syncthreads();
+    if (t < 32) {
+      const float a = ((red[t] + red[32 + t]) + red[64 + t]) + red[96 + t];
+      const float c = ((red[128 + t] + red[160 + t]) + red[192 + t]) + red[224 + t];
+      ep.bn_part[((long long)0 * CF_K + t) * d.B + b] = a;
+      ep.bn_part[((long long)1 * CF_K + t) * d.B + b] = c;
+    }
+  }
+}
+
+// geometry / epilogue the per-image kernel covers
+static bool conv_first_ok(const AliConvGeom* g, const AliEpilogue* ep, bool f16) {
+  if (g->C != CF_C || g->K != CF_K || g->stride != 1 || g->pad != 0 || g->R != g->S || (g->R != 5 && g->R != 3)) return false;
+  if (g->H > 32 || g->W > 32 || g->B < 64 || f16) return false;
+  if (g->P != g->H - g->R + 1 || g->Q != g->W - g->S + 1) return false;
+  if (ep && (ep->mask || ep->dact_y || (ep->bn_part && ep->bn_mode != 1))) return false;
+  if (ep && ep->bn_part && ep->bn_groups > 1 && g->B % ep->bn_groups != 0) return false;
+  return true;
+}
+
+static int conv_first_launch(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
+                             hipStream_t stream) {
+  CFDesc d;
+  memset(&d, 0, sizeof(d));
+  d.in = x; d.w = w; d.out = y;
+  if (ep) d.ep = *ep;
+  d.B = g->B; d.H = g->H; d.W = g->W; d.P = g->P; d.Q = g->Q; d.R = g->R; d.S = g->S;
+  const size_t lds = ((size_t)g->H * g->W * CF_PIXLD + (size_t)CF_K * CF_WLD + 256) * sizeof(float);
+  if (g->R == 5) hipLaunchKernelGGL((conv_first_kernel<25>), dim3(g->B), dim3(256), lds, stream, d);
+  else hipLaunchKernelGGL((conv_first_kernel<9>), dim3(g->B), dim3(256), lds, stream, d);
+  return check_launch("conv_first_kernel");
+}
+
 static void setup_fwd(const AliConvGeom* g, GDesc& d) {
   d.B = g->B; d.Hin = g->H; d.Win = g->W; d.Cin = g->C;
   d.Hout = g->P; d.Wout = g->Q; d.Cout = g->K; d.ldo = g->K;
@@ -1091,6 +1206,11 @@ static bool setup_bwd_data(const AliConvGeom* g, GDesc& d) {
 extern "C" int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* tile_rows,
                                    int32_t* pixel_major) {
   if (!geom_ok(g) || (which != 0 && which != 1)) return 0;
+  if (which == 0 && conv_first_ok(g, nullptr, mfma_f16 != 0)) {      // per-image kernel: one slot per image
+    if (tile_rows) *tile_rows = g->P * g->Q;
+    if (pixel_major) *pixel_major = 0;
+    return g->B;
+  }
   GDesc d;
   memset(&d, 0, sizeof(d));
   d.f16 = mfma_f16 != 0;
@@ -1115,6 +1235,13 @@ extern "C" int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which) {
 extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
                             void* ws, size_t ws_bytes, ali_stream_t stream) {
   if (!geom_ok(g) || !x || !w || !y) { set_error("ali_conv_fwd: bad argument"); return ALI_ERR_BAD_ARG; }
+  if (conv_first_ok(g, nullptr, ep && ep->mfma_f16)) {
+    // (the slot count ali_conv_mtiles reports depends on the geometry alone: an epilogue the per-image kernel cannot
+    // serve is an error here rather than a silent change of the partial layout)
+    if (conv_first_ok(g, ep, false)) return conv_first_launch(g, x, w, y, ep, (hipStream_t)stream);
+    if (ep && ep->bn_part) { set_error("ali_conv_fwd: epilogue not supported for this first-layer geometry"); return ALI_ERR_BAD_ARG; }
+    // (no partials requested: the GEMM kernel serves the epilogue the per-image kernel cannot)
+  }
   GDesc d;
   memset(&d, 0, sizeof(d));
   d.in = x; d.w = w; d.out = y;

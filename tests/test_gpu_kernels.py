@@ -54,6 +54,7 @@ CONV_CASES = [
     (2, 7, 32, 16, 5, 2, 1), (3, 16, 15, 32, 5, 2, 1), (3, 32, 7, 64, 5, 2, 1), (5, 64, 3, 128, 5, 2, 1),
     (1, 3, 37, 8, 5, 2, 1),
     (512, 256, 3, 512, 4, 2, 1),   # split-K path at the bench batch
+    (70, 5, 28, 32, 5, 1, 0), (64, 7, 20, 32, 3, 1, 0),   # per-image first-layer kernel (B >= 64, 8 -> 32 channels)
 ]
 
 
