@@ -72,6 +72,8 @@ struct GDesc {
   int Hout, Wout, Cout, ldo;
   int ldw, S;          // weight row stride (floats), kernel width (taps per kernel row)
   int nphase, splitk, kt_per_split;
+  int ntile_m, ntile_n;     // m-tiles (all phases) and n-tiles of the launch
+  int tail_u0, tail_split;  // tail-split launches (tail_split > 1): see the kernel's block-index decoding
   int f16;             // AliEpilogue.mfma_f16: fp16 operands on v_mfma_f32_32x32x16_f16 where the fast path applies
   const _Float16* in16;   // AliEpilogue.in16 / w16 / out16 (fp16 twins of in / w / out), or null
   const _Float16* w16;
@@ -126,13 +128,32 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+  // Which (m-tile bx, n-tile by, k-slice bz of nsplit) this block is.  Plain launches: the 3-D block index.  "Tail split"
+  // launches (all-resident grids of 1-4 tiles per CU, see finalize_and_launch): a 1-D grid whose first tail_u0 blocks
+  // take one whole tile each (multiples of the CU count: every CU the same number) and whose remaining blocks share
+  // the left-over tiles tail_split ways along K -- so the left-over costs every CU 1/tail_split of a tile instead of
+  // costing a few CUs a whole one while the rest idle.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nsplit = d.splitk;
+  if (d.tail_split > 1) {
+    int u = blockIdx.x;
+    bz = 0;
+    nsplit = 1;
+    if (u >= d.tail_u0) {
+      const int r = u - d.tail_u0;
+      u = d.tail_u0 + r / d.tail_split;
+      bz = r - (r / d.tail_split) * d.tail_split;
+      nsplit = d.tail_split;
+    }
+    by = u / d.ntile_m;
+    bx = u - by * d.ntile_m;
+  }
   int p = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i)
-    if (i < d.nphase && (int)blockIdx.x >= d.ph[i].tile0) p = i;
+    if (i < d.nphase && bx >= d.ph[i].tile0) p = i;
   const Phase& P = d.ph[p];
-  const int m0 = ((int)blockIdx.x - P.tile0) * BM;
-  const int n0 = blockIdx.y * BN;
+  const int m0 = (bx - P.tile0) * BM;
+  const int n0 = by * BN;
   const int Cin = d.Cin, Hin = d.Hin, Win = d.Win;
   const int ntaps = P.nr * P.ns;
 
@@ -257,8 +278,8 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     const int cpt = MODE == 3 ? 1 : Cin / BK;
     const int nlive = MODE == 3 ? (ntaps + tpt - 1) / tpt : __popc(tapmask);
     const int total = nlive * cpt;
-    const int per = (total + d.splitk - 1) / d.splitk;
-    const int qb = blockIdx.z * per;
+    const int per = (total + nsplit - 1) / nsplit;
+    const int qb = bz * per;
     const int qe = min(total, qb + per);
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, d.in_bytes, 0x00020000);
@@ -302,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
       constexpr int BK16 = 64;
       const int cpt16 = Cin / BK16;
       const int total16 = nlive * cpt16;
-      const int per16 = (total16 + d.splitk - 1) / d.splitk;
-      const int qb16 = blockIdx.z * per16;
+      const int per16 = (total16 + nsplit - 1) / nsplit;
+      const int qb16 = bz * per16;
       const int qe16 = min(total16, qb16 + per16);
       const __amdgpu_buffer_rsrc_t rin16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.in16, 0, d.in_bytes / 2, 0x00020000);
       const __amdgpu_buffer_rsrc_t rw16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w16, 0, d.w_bytes / 2, 0x00020000);
@@ -766,11 +787,11 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
           a += red[(0 * WAVES_M + w) * BN + t];
           b += red[(1 * WAVES_M + w) * BN + t];
         }
-        int slot = blockIdx.x;
-        const int nslots = gridDim.x;
+        int slot = bx;
+        const int nslots = d.ntile_m;
         if (ep.bn_groups > 1 && P.pixmajor) {   // tiles of one pixel position: images [0,B) in order, passes back to back
           const int tpp = d.B / BM, tpg = tpp / ep.bn_groups;
-          const int pix = (int)blockIdx.x / tpp, tin = (int)blockIdx.x - pix * tpp;
+          const int pix = bx / tpp, tin = bx - pix * tpp;
           const int grp = tin / tpg;
           slot = grp * (nslots / ep.bn_groups) + pix * tpg + (tin - grp * tpg);
         }
@@ -784,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   using BN2 = std::integral_constant<int, 2>;
   using T_ = std::true_type;
   using F_ = std::false_type;
-  if (d.splitk > 1) {
+  if (nsplit > 1) {
     // split-K: every block stores its raw partial tile in its slab; the block that arrives last at the tile's
     // counter sums the slabs in slab order (deterministic whichever block that is) and runs the real epilogue.
     // Slab stores / loads are device-scope (sc1) accesses -- written through to memory, never served from another
@@ -803,14 +824,14 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     //     launch.  The counter is reset by the winner alone, after all arrivals: the next launch (stream order)
     //     finds it at zero.
     // Nothing else is shared between the blocks of a tile, so no cache-wide fence is required.
-    run_epilogue(F_{}, F_{}, BN0{}, true, d.ws + (long long)blockIdx.z * d.out_elems);
+    run_epilogue(F_{}, F_{}, BN0{}, true, d.ws + (long long)bz * d.out_elems);
     __shared__ int s_last;
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (t == 0) {
-      int* c = d.ctr + (blockIdx.y * gridDim.x + blockIdx.x);
+      int* c = d.ctr + (by * d.ntile_m + bx);
       const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = arrived == d.splitk - 1;
+      s_last = arrived == nsplit - 1;
       if (s_last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all blocks have arrived
     }
     __syncthreads();
@@ -818,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     // all 16 rows x 4 slabs of a sub-tile are requested before the first one is consumed (the loads bypass L2:
     // one memory latency per 4 slabs instead of one per slab).  Buffer loads: 32-bit offsets, invalid rows -> 0.
     const __amdgpu_buffer_rsrc_t rws =
-        __builtin_amdgcn_make_buffer_rsrc((void*)d.ws, 0, (unsigned)(d.splitk * d.out_elems * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)d.ws, 0, (unsigned)(nsplit * d.out_elems * 4), 0x00020000);
     constexpr int kSc1 = 16;          // cache policy: device scope
     const unsigned slab_bytes = (unsigned)(d.out_elems * 4);
 #pragma unroll
@@ -837,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
         for (int r = 0; r < 16; ++r) v[r] = 0.f;
         // (the bounds check of a buffer load covers voffset only: every soffset used here is a real slab)
         int sl0 = 0;
-        for (; sl0 + 4 <= d.splitk; sl0 += 4) {
+        for (; sl0 + 4 <= nsplit; sl0 += 4) {
           float tmp[4][16];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -851,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += tmp[u][r];
         }
-        for (; sl0 < d.splitk; ++sl0) {
+        for (; sl0 < nsplit; ++sl0) {
           const unsigned soff = (unsigned)sl0 * slab_bytes;
           float tmp[16];
 #pragma unroll
@@ -984,9 +1005,29 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   d.splitk = S;
   d.kt_per_split = (max_nkt + S - 1) / S;
   if (d.kt_per_split < 1) d.kt_per_split = 1;
+  d.ntile_m = tiles;
+  d.ntile_n = ntile_n;
+  // Tail split.  A grid of 1-4 tiles per CU is resident all at once and lasts as long as the fullest CU: 576 tiles on
+  // 256 CUs cost 3 tile-times although the chip only has 2.25 to do.  The first floor(blocks / CUs) * CUs tiles run
+  // whole; the R left-over tiles are cut Sr ways along K (Sr * R <= CUs: one piece per CU), folded in the kernel
+  // like any split-K tile.  Only those R tiles pay slab traffic.  (uniform-tap loops only; fp32 and fp16 alike)
+  d.tail_split = 1;
+  d.tail_u0 = 0;
+  if (S == 1 && uni && ws && blocks > kNumCU && blocks < 4 * kNumCU && blocks <= (long long)(kWsReserved / sizeof(int))
+      && tuning().splitk == 0) {
+    const int R = (int)(blocks % kNumCU);
+    int Sr = 1;
+    while (R > 0 && Sr * 2 <= 8 && Sr * 2 * R <= kNumCU && max_nkt / (Sr * 2) >= 4) Sr *= 2;
+    if (Sr > 1 && (size_t)Sr * d.out_elems * sizeof(float) <= ws_payload_bytes(ws_bytes) &&
+        (long long)Sr * d.out_elems * 4 < 0xFF000000LL) {
+      d.tail_split = Sr;
+      d.tail_u0 = (int)(blocks - R);
+    }
+  }
   d.ctr = reinterpret_cast<int*>(ws);
   d.ws = reinterpret_cast<float*>(ws_payload(ws));
   dim3 grid(tiles, ntile_n, S), block(256);
+  if (d.tail_split > 1) grid = dim3(d.tail_u0 + (int)(blocks - d.tail_u0) * d.tail_split, 1, 1);
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
   const bool f16 = d.f16 && uni;
   const bool op16 = f16 && d.in16 && d.w16 && (d.Cin % 64) == 0;
