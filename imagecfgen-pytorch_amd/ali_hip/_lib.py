@@ -26,7 +26,8 @@ class AliEpilogue(Structure):
                 ("bn_part", c_void_p), ("bn_mode", c_int32), ("bn_groups", c_int32), ("bn_stat_mask", c_void_p),
                 ("bn_mask_ld", c_int32), ("bn_x", c_void_p), ("bn_mean", c_void_p), ("bn_invstd", c_void_p),
                 ("bn_mask_in", c_void_p), ("bn_mask_pre", c_void_p), ("mfma_f16", c_int32),
-                ("in16", c_void_p), ("w16", c_void_p), ("out16", c_void_p)]
+                ("in16", c_void_p), ("w16", c_void_p), ("out16", c_void_p),
+                ("tile_order", c_void_p), ("tile_order_n", c_int32), ("in_ld", c_int32), ("out_ld", c_int32)]
 
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
@@ -36,13 +37,14 @@ SIGNATURES = {
     "ali_conv_workspace_bytes": (c_size_t, [POINTER(AliConvGeom), c_int32]),
     "ali_conv_mtiles": (c_int32, [POINTER(AliConvGeom), c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "ali_conv_writes_out16": (c_int32, [POINTER(AliConvGeom), c_int32]),
+    "ali_conv_tile_order": (c_int32, [POINTER(AliConvGeom), c_int32, c_int32, c_void_p, c_int32]),
     "ali_conv_fwd": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue), c_void_p,
                                c_size_t, c_void_p]),
     "ali_conv_bwd_data": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue),
                                     c_void_p, c_size_t, c_void_p]),
     "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
-                                      c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
-                                      c_void_p]),
+                                      c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
+                                      c_size_t, c_void_p]),
     "ali_wgrad_pixtab": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p]),
     "ali_pack_weights": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
                                    c_void_p]),
@@ -90,6 +92,7 @@ SIGNATURES = {
                          + [c_int32] * 7 + [c_void_p, c_size_t, c_void_p]),
     "ali_last_error": (c_char_p, []),
     "ali_version": (c_int32, []),
+    "ali_reload_tuning": (None, []),
 }
 
 _lib = None

@@ -316,8 +316,24 @@ def slice_saved(saved, group: int, groups: int):
     return out
 
 
-def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool, groups: int = 1):
+def join_ok(plan: ChainPlan) -> bool:
+    """Can the chain's last stage write its output straight into a column range of a wider row-major buffer
+    (``chain_forward(join=...)``) and take its output gradient from one (``chain_backward(gy_ld=...)``)?  A plain
+    Conv2d GEMM ending in no activation / LeakyReLU (the ends of D.dx and D.dz, mnist.py:116-123)."""
+    st = plan.stages[-1]
+    return (len(plan.stages) > 1 and st.kind == "conv" and st.act in (ACT_NONE, ACT_LEAKY)
+            and st.mod.out_channels % 4 == 0 and st.mod.in_channels % 4 == 0)
+
+
+def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool, groups: int = 1,
+                  join=None, first_mask_applied: bool = False):
     """x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list).
+
+    ``join`` = (joint [B, Ctot] fp32, column offset, mask [B, Ctot] or None): the last stage (``join_ok``; output map
+    1x1) writes act(conv) * mask[:, off:off+K] into joint[:, off:off+K] instead of a tensor of its own -- the
+    concatenation and the Dropout2d in front of the consuming chain cost no launch (mnist.py:152-154).
+    ``first_mask_applied``: the input already carries the first stage's Dropout2d mask (it was folded into the
+    producers that way); the mask is still drawn, in order, and saved for the backward pass.
 
     ``groups`` > 1: the batch holds that many independent forward passes back to back (equal sample counts).  The
     convolutions run once over all of them; BatchNorm takes its batch statistics -- and updates the running ones --
@@ -334,8 +350,8 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
         kinds = [p[0] for p in st.pre]
         mask = None
         bn = None
-        mask_applied = folded is not None
-        if mask_applied:
+        mask_applied = folded is not None or (si == 0 and first_mask_applied)
+        if folded is not None:
             mask, folded = folded, None
         elif early is not None:
             mask, early = early, None
@@ -371,8 +387,18 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             t = ops.rowmask_mul(cur, mask, B, rows, Cp)
         out_shape = _out_shape(st, B, H, W, Cp)
         g = _geom(st, (B, H, W, Cp), out_shape)
-        y = torch.empty(out_shape, dtype=torch.float32, device=cur.device)
         nxt = plan.stages[si + 1] if si + 1 < len(plan.stages) else None
+        out_ld = 0
+        jmask = None
+        if nxt is None and join is not None:
+            joint, joff, jm = join
+            if out_shape[1] != 1 or out_shape[2] != 1 or joint.shape[0] != B or not join_ok(plan):
+                raise ValueError("chain_forward(join=...): the last stage must be a plain conv GEMM onto a 1x1 map")
+            out_ld = joint.shape[1]
+            y = joint[:, joff:joff + out_shape[3]].unflatten(1, (1, 1, out_shape[3]))     # [B,1,1,K] view, rows out_ld apart
+            jmask = None if jm is None else jm[:, joff:joff + out_shape[3]]
+        else:
+            y = torch.empty(out_shape, dtype=torch.float32, device=cur.device)
         nk = [p[0] for p in nxt.pre] if nxt is not None else []
         plain_gemm = st.kind in ("conv", "convT") and not _is_tconv1(st, Cp) and not _scatter_fwd(st, Cp)
         # A lone Dropout2d in front of the next stage multiplies this stage's output by a per-(sample, channel)
@@ -397,6 +423,8 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
                     bn_part = (part, slots)
                     bn_fwd = (part, groups, early)
         ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope, mask=folded, bn_fwd=bn_fwd)
+        if jmask is not None:
+            ep.mask, ep.mask_ld = jmask.data_ptr(), jmask.stride(0)
         if _scatter_fwd(st, Cp) and folded is None:    # (measured 12 us faster than tconv1_fwd on the MNIST tail, too)
             m = st.mod
             R, S = m.kernel_size
@@ -413,7 +441,7 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
         elif st.kind == "convT":
             ops.conv_bwd_data(g, t, plan.packed(st, "fwd", Cp), y, ep)
         else:
-            ops.conv_fwd(g, t, plan.packed(st, "fwd", Cp), y, ep)
+            ops.conv_fwd(g, t, plan.packed(st, "fwd", Cp), y, ep, out_ld=out_ld)
         sv.t, sv.y, sv.geom, sv.in_shape, sv.out_shape = t, y, g, (B, H, W, Cp), out_shape
         if save:
             saved.append(sv)
@@ -423,18 +451,27 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
 
 
 def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True,
-                   grad_dst=None, gx_planes=None):
+                   grad_dst=None, gx_planes=None, gy_ld: int = 0, gy_pre: bool = False, in_act=None):
     """Returns (gx or None, {param tensor id -> grad}).  ``grad_dst`` optionally maps id(param) to a
     preallocated destination (a view of a flat gradient buffer) that the kernels write directly.
     ``gx_planes`` (hand-scheduled step only): instead of the full input gradient return only these input
     channels of it, as a [B,H,W,len(gx_planes)] tensor -- the first layer's data gradient is consumed one plane
-    at a time (image plane towards G, embedding plane towards the digit table)."""
+    at a time (image plane towards G, embedding plane towards the digit table).
+    ``gy_ld`` > 0 (needs ``join_ok``): ``gy`` is a column range (strided view, rows ``gy_ld`` floats apart) of a wider
+    buffer; ``gy_pre``: it already is the gradient of the last stage's PRE-activation.  ``in_act`` = (act, slope) of the
+    activation that produced this chain's input ``x`` (the ends of the chains whose outputs were joined): the returned
+    gradient is then the one of their pre-activations, computed by the first stage's data-gradient epilogue."""
     grads = {}
     grad_dst = grad_dst or {}
     n = len(plan.stages)
     last = plan.stages[-1]
-    gy = gy.contiguous()
-    g_pre = ops.act_bwd(gy, saved[-1].y, last.act, last.slope) if last.act != ACT_NONE else gy
+    if gy_ld:
+        if not (gy_pre or last.act == ACT_NONE) or not join_ok(plan):
+            raise ValueError("chain_backward(gy_ld=...): needs join_ok(plan) and a pre-activation gradient")
+        g_pre = gy
+    else:
+        gy = gy.contiguous()
+        g_pre = gy if (gy_pre or last.act == ACT_NONE) else ops.act_bwd(gy, saved[-1].y, last.act, last.slope)
     gx = None
     for i in range(n - 1, -1, -1):
         st, sv = plan.stages[i], saved[i]
@@ -444,6 +481,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
         rows_out = B * P * Q
         m = st.mod
         g = sv.geom
+        ld = gy_ld if i == n - 1 else 0          # pixel pitch of g_pre (0 = dense)
         prev = plan.stages[i - 1] if i > 0 else None
         c_in_log = prev.mod.out_channels if (prev is not None and prev.kind != "linear") else (
             (prev.unflat[0] if prev.unflat else prev.mod.out_features) if prev is not None else c_log_in)
@@ -473,7 +511,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                                  m.kernel_size[0], m.kernel_size[1], m.padding[0])
             elif st.kind == "conv":
                 T = m.kernel_size[0] * m.kernel_size[1]
-                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1, db=fused_db)
+                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1, db=fused_db, dy_ld=ld)
             elif _is_tconv1(st, Cp):
                 T = m.kernel_size[0] * m.kernel_size[1]
                 ops.tconv1_wgrad(sv.t, g_pre, 1, 1, dw, T, 1, 0, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1],
@@ -520,7 +558,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             break
         if i == 0 and not need_gx and sv.bn is None:
             break
-        pact, pslope = (prev.act, prev.slope) if prev is not None else (ACT_NONE, 0.0)
+        pact, pslope = (prev.act, prev.slope) if prev is not None else (in_act or (ACT_NONE, 0.0))
         gt = torch.empty(sv.in_shape, dtype=torch.float32, device=gy.device)
         bn_red = None
         if sv.bn is None:
@@ -543,7 +581,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
         elif st.kind == "convT":
             ops.conv_fwd(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)
         else:
-            ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)
+            ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep, in_ld=ld)
         if sv.bn is not None:
             bn = sv.bn
             use_batch = sv.training or bn.running_mean is None

@@ -96,6 +96,32 @@ def _pad(mask, cpad):
     return out
 
 
+def peek_mask(skip: int, B: int, C: int, p: float, device, cpad=None):
+    """The mask ``next_mask(B, C, p, device, cpad)`` will return after ``skip`` more requests, without consuming
+    anything -- or None when it cannot be known yet (masks drawn one launch at a time: first iteration of a stepper,
+    changed request sequence).  The caller must still request it in its turn."""
+    cpad = C if cpad is None else cpad
+    inj = _state["inject"]
+    if inj is not None:
+        i = _state["pos"] + skip
+        if i + _state["pair"] >= len(inj) + (0 if _state["pair"] else 1):
+            return None
+        m = inj[i]
+        if _state["pair"]:
+            m = torch.cat([m, inj[i + _state["pair"]]], dim=0)
+        if tuple(m.shape) != (B, C):
+            return None
+        return _pad(m.to(device=device, dtype=torch.float32).contiguous(), cpad)
+    plan, rec = _state["plan"], _state["record"]
+    if plan is None or rec is not None:
+        return None
+    i = _state["req"] + skip
+    if i >= len(plan["req"]) or plan["req"][i] != (B, C, p, cpad):
+        return None
+    lo = plan["ends"][i] - B * cpad
+    return plan["buf"][lo:lo + B * cpad].view(B, cpad)
+
+
 def next_mask(B: int, C: int, p: float, device, cpad=None) -> torch.Tensor:
     """[B, cpad] mask of the next Dropout2d: columns < C are Bernoulli(1-p)/(1-p), channel-padding columns are 1."""
     cpad = C if cpad is None else cpad

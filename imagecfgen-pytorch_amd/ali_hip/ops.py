@@ -227,37 +227,78 @@ def _twin_for_pack(dst):
 
 
 def _f16_operands(g, which, x, w_packed, y, ep):
-    """fp16 twins for a precision("f16") launch: read them where both operands have one, leave one of the output."""
+    """fp16 twins for a precision("f16") launch: read them where both operands have one, leave one of the output.
+    (Column-range operands -- in_ld / out_ld -- neither read nor leave twins.)"""
     if not _PRECISION["f16"]:
         return
-    x16, w16 = shadow16(x), shadow16(w_packed)
+    x16, w16 = (None if ep.in_ld else shadow16(x)), shadow16(w_packed)
     if x16 is not None and w16 is not None:
         ep.in16, ep.w16 = c_void_p(x16.data_ptr()), c_void_p(w16.data_ptr())
-    if _lib.load().ali_conv_writes_out16(byref(g), which):
+    if not ep.out_ld and _lib.load().ali_conv_writes_out16(byref(g), which):
         y16 = torch.empty(y.shape, dtype=torch.float16, device=y.device)
         ep.out16 = c_void_p(y16.data_ptr())
         y._ali16 = y16
 
 
-def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue):
+_TILE_ORDER = {}
+
+
+def conv_tile_order(g: AliConvGeom, which: int, device):
+    """Cached device table of the launch's M-tile ids, longest k-loop first (include/ali_hip.h: ali_conv_tile_order),
+    or None when every tile costs the same.  Built on the host: a miss while the stream is capturing returns None
+    (the eager warm-up iteration in front of every capture fills the cache)."""
+    f16 = int(_PRECISION["f16"])
+    key = (device.index, which, f16) + tuple(getattr(g, n) for n, _ in AliConvGeom._fields_)
+    if key in _TILE_ORDER:
+        return _TILE_ORDER[key]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    cap = 1 << 16
+    buf = (ctypes.c_int32 * cap)()
+    n = _lib.load().ali_conv_tile_order(byref(g), which, f16, ctypes.cast(buf, c_void_p), cap)
+    tab = torch.tensor(list(buf[:n]), dtype=torch.int32, device=device) if n > 0 else None
+    _TILE_ORDER[key] = tab
+    return tab
+
+
+def _set_tile_order(g, which, ep, device):
+    tab = conv_tile_order(g, which, device)
+    if tab is not None:
+        ep.tile_order, ep.tile_order_n = tab.data_ptr(), tab.numel()
+
+
+def _view_ptr(t, ld, name):
+    """pointer of a dense tensor (ld == 0) or of a column range of rows ``ld`` floats apart (a strided view)"""
+    return _ptr(t) if ld else _chk(t, name)
+
+
+def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue, in_ld=0, out_ld=0):
+    """``in_ld`` / ``out_ld`` > 0: ``x`` / ``y`` are column ranges (strided views) of wider row-major buffers whose
+    pixels are that many floats apart (AliEpilogue.in_ld / out_ld)."""
     lib = _lib.load()
     ws = workspace(x.device)
+    ep.in_ld, ep.out_ld = in_ld, out_ld
     _f16_operands(g, 0, x, w_packed, y, ep)
+    _set_tile_order(g, 0, ep, x.device)
 
     def go():
-        _lib.check(lib.ali_conv_fwd(byref(g), _chk(x, "x"), _chk(w_packed, "w"), _chk(y, "y"), byref(ep),
+        _lib.check(lib.ali_conv_fwd(byref(g), _view_ptr(x, in_ld, "x"), _chk(w_packed, "w"), _view_ptr(y, out_ld, "y"),
+                                    byref(ep),
                                     c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
     _launch("gconv", *_geom_cost(g), go)
     return y
 
 
-def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue):
+def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue, in_ld=0, out_ld=0):
     lib = _lib.load()
     ws = workspace(dy.device)
+    ep.in_ld, ep.out_ld = in_ld, out_ld
     _f16_operands(g, 1, dy, w_packed, dx, ep)
+    _set_tile_order(g, 1, ep, dy.device)
 
     def go():
-        _lib.check(lib.ali_conv_bwd_data(byref(g), _chk(dy, "dy"), _chk(w_packed, "w"), _chk(dx, "dx"), byref(ep),
+        _lib.check(lib.ali_conv_bwd_data(byref(g), _view_ptr(dy, in_ld, "dy"), _chk(w_packed, "w"),
+                                         _view_ptr(dx, out_ld, "dx"), byref(ep),
                                          c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
     _launch("gconv_t", *_geom_cost(g), go)
     return dx
@@ -279,23 +320,25 @@ def wgrad_pixtab(g: AliConvGeom, device):
     return tab
 
 
-def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap, db=None):
-    """``db`` (optional, [cd_log]): also produce the column sums of ``dy`` (Conv2d bias gradient) in the same launch."""
+def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap, db=None, dy_ld=0):
+    """``db`` (optional, [cd_log]): also produce the column sums of ``dy`` (Conv2d bias gradient) in the same launch.
+    ``dy_ld`` > 0: ``dy`` is a column range (a strided view) of rows that are ``dy_ld`` floats apart."""
     lib = _lib.load()
     ws = workspace(x.device)
     tab = wgrad_pixtab(g, x.device) if (g.C % 4 == 0 and g.K % 4 == 0) else None
     f16 = int(_PRECISION["f16"])
-    x16, dy16 = (shadow16(x), shadow16(dy)) if f16 else (None, None)
+    x16, dy16 = (shadow16(x), shadow16(dy)) if (f16 and not dy_ld) else (None, None)
     if x16 is None or dy16 is None:
         x16 = dy16 = None
 
     def go():
-        _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _chk(dy, "dy"), _chk(dst, "dst"), cg_log, cd_log,
+        _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _ptr(dy) if dy_ld else _chk(dy, "dy"),
+                                           _chk(dst, "dst"), cg_log, cd_log,
                                            s_dc, s_gc, s_tap, _opt(db, "db"),
                                            None if tab is None else c_void_p(tab.data_ptr()), f16,
                                            None if x16 is None else c_void_p(x16.data_ptr()),
-                                           None if dy16 is None else c_void_p(dy16.data_ptr()), c_void_p(ws.data_ptr()),
-                                           ws.numel(), _stream()), "ali_conv_bwd_weight")
+                                           None if dy16 is None else c_void_p(dy16.data_ptr()), dy_ld,
+                                           c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_weight")
     _launch("wgrad", *_geom_cost(g), go)
     return dst
 

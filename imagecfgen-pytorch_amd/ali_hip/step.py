@@ -182,6 +182,17 @@ class AliStepper:
         self._emb_planes = tuple(range(1, 1 + len(self.family.d_tables)))
         self._n_drop = sum(1 for pl in (self.pDx, self.pDz, self.pDxz) for st in pl.stages
                            if any(k == "drop" for k, _ in st.pre))
+        # D's joint rows [dx | dz] (mnist.py:152-154): when both branches end in a plain conv GEMM + the same
+        # activation and dxz starts with a lone Dropout2d, the branch ends write straight into the joint buffer
+        # (masked), and dxz's first data gradient returns the branches' pre-activation gradients -- no torch.cat, no
+        # mask pass, no slice copies, no act' passes around the join
+        lx, lz, f0 = self.pDx.stages[-1], self.pDz.stages[-1], self.pDxz.stages[0]
+        self._join = (_chain.join_ok(self.pDx) and _chain.join_ok(self.pDz) and (lx.act, lx.slope) == (lz.act, lz.slope)
+                      and f0.kind == "conv" and [k for k, _ in f0.pre] == ["drop"]
+                      and f0.mod.in_channels == lx.mod.out_channels + lz.mod.out_channels
+                      and tuple(f0.mod.kernel_size) == (1, 1))
+        self._join_act = (lx.act, lx.slope)
+        self._join_skip = sum(1 for pl in (self.pDx, self.pDz) for st in pl.stages if any(k == "drop" for k, _ in st.pre))
 
     # ------------------------------------------------------------------ pieces
     def _planes(self, X, idx, cont, tables, out=None):
@@ -213,13 +224,40 @@ class AliStepper:
     def _g_input(self, z, onehots, cont):
         return _g_input(self.family, z, onehots, cont)
 
-    def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None):
+    def _join_begin(self, B, device):
+        """(joint buffer [B, n_dx + nz], the Dropout2d mask of dxz's first stage) for a D forward that is about to
+        start with its dx chain, or None: the mask has to be known before the branches run, i.e. it is looked up ahead
+        of its turn (injected tapes, the per-iteration mask plan) -- never drawn out of order."""
+        if not self._join:
+            return None
+        ctot = self.pDxz.stages[0].mod.in_channels
+        mask = _dropout.peek_mask(self._join_skip, B, ctot, self.pDxz.stages[0].pre[0][1], device, ctot)
+        if mask is None:
+            return None
+        return torch.empty(B, ctot, dtype=torch.float32, device=device), mask
+
+    def _dx_forward(self, x0, n_log, save, groups=1):
+        """D.dx, writing its end into the joint buffer when the chains can join: (dx_pre, join) for _d_forward"""
+        join = self._join_begin(x0.shape[0], x0.device)
+        dx_pre = chain_forward(self.pDx, x0, True, n_log, save, groups,
+                               join=None if join is None else (join[0], 0, join[1]))
+        return dx_pre, join
+
+    def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None, join=None):
         B = x0.shape[0]
-        dx, s_dx = dx_pre if dx_pre is not None else chain_forward(self.pDx, x0, True, n_log, save, groups)
-        dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups)
-        joint = torch.cat([dx.reshape(B, -1), dz.reshape(B, -1)], dim=1).reshape(B, 1, 1, -1)
-        logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups)
-        return logit.reshape(B, 1), (s_dx, s_dz, s_dxz, dx.shape[-1], n_log)
+        if dx_pre is None:
+            dx_pre, join = self._dx_forward(x0, n_log, save, groups)
+        dx, s_dx = dx_pre
+        n_dx = dx.shape[-1]
+        dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups,
+                                 join=None if join is None else (join[0], n_dx, join[1]))
+        if join is None:
+            joint = torch.cat([dx.reshape(B, -1), dz.reshape(B, -1)], dim=1).reshape(B, 1, 1, -1)
+            logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups)
+        else:
+            joint = join[0].reshape(B, 1, 1, -1)
+            logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups, first_mask_applied=True)
+        return logit.reshape(B, 1), (s_dx, s_dz, s_dxz, n_dx, n_log)
 
     def _d_forward_pair(self, x0a, zina, x0b, zinb, n_log, save, x0_pair=None):
         """D(a) and D(b) with the same weights as ONE batch of 2B samples (rows [0,B) = a): half the launches, and
@@ -236,17 +274,30 @@ class AliStepper:
         B = glogit.shape[0]
         dst = self.opt_d.grad_views if need_params else None
         gjoint, _ = chain_backward(self.pDxz, s_dxz, glogit.reshape(B, 1, 1, 1), s_dxz[0].in_shape[3], True,
-                                   need_params, dst)
+                                   need_params, dst, **self._join_in())
         gjoint = gjoint.reshape(B, -1)
         gx0 = gz = None
         if need_params or need_x:
-            gx0, _ = chain_backward(self.pDx, s_dx, gjoint[:, :n_dx].contiguous().reshape(B, 1, 1, n_dx), n_log,
-                                    need_x, need_params, dst, gx_planes=planes if need_x else None)
+            gx0, _ = chain_backward(self.pDx, s_dx, *self._branch_grad(gjoint, 0, B, 0, n_dx), n_log,
+                                    need_x, need_params, dst, gx_planes=planes if need_x else None,
+                                    **self._join_out(gjoint))
         if need_params or need_z:
             nz = gjoint.shape[1] - n_dx
-            gz, _ = chain_backward(self.pDz, s_dz, gjoint[:, n_dx:].contiguous().reshape(B, 1, 1, nz), nz, need_z,
-                                   need_params, dst)
+            gz, _ = chain_backward(self.pDz, s_dz, *self._branch_grad(gjoint, 0, B, n_dx, nz), nz, need_z,
+                                   need_params, dst, **self._join_out(gjoint))
         return gx0, gz
+
+    # the join in the backward pass: dxz's first data-gradient epilogue applies the branch ends' act', the branches
+    # read their column range of the joint gradient in place (otherwise: slice copies + act' passes)
+    def _join_in(self):
+        return {"in_act": self._join_act} if self._join else {}
+
+    def _join_out(self, gjoint):
+        return {"gy_ld": gjoint.shape[1], "gy_pre": True} if self._join else {}
+
+    def _branch_grad(self, gjoint, r0, rows, c0, cols):
+        g = gjoint[r0:r0 + rows, c0:c0 + cols]
+        return ((g if self._join else g.contiguous()).unflatten(1, (1, 1, cols)),)
 
     # ------------------------------------------------------------------ the iteration, phase by phase
     def _begin(self, images, c, z, do_eg=True):
@@ -274,21 +325,22 @@ class AliStepper:
         l3, gl = ops.bce_logits_pair(logits, B, 0.0, 1.0, 0.5 * self.loss_scale)
         cx["out"]["loss_eg"] = l3[0]
         # backward: dxz for both passes at once (data gradient only: D is not updated in this phase) ...
-        gjoint, _ = chain_backward(self.pDxz, s_dxz, gl.reshape(2 * B, 1, 1, 1), s_dxz[0].in_shape[3], True, False)
+        gjoint, _ = chain_backward(self.pDxz, s_dxz, gl.reshape(2 * B, 1, 1, 1), s_dxz[0].in_shape[3], True, False,
+                                   **self._join_in())
         gjoint = gjoint.reshape(2 * B, -1)
         dst = self.opt_eg.grad_views
         # ... real pass: only the z-side path (dxz -> dz) reaches E
         nz = gjoint.shape[1] - n_dx
-        g_ex, _ = chain_backward(self.pDz, slice_saved(s_dz, 0, 2), gjoint[:B, n_dx:].contiguous().reshape(B, 1, 1, nz),
-                                 nz, True, False)
+        g_ex, _ = chain_backward(self.pDz, slice_saved(s_dz, 0, 2), *self._branch_grad(gjoint, 0, B, n_dx, nz),
+                                 nz, True, False, **self._join_out(gjoint))
         # of E's input gradient only the embedding planes are consumed (their tables are parameters of E)
         g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, bool(self._emb_planes), True, dst,
                                   gx_planes=self._emb_planes or None)
         if self._emb_planes:
             self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
         # ... fake pass: only the image path (dxz -> dx) reaches G
-        g_x0f, _ = chain_backward(self.pDx, slice_saved(s_dx, 1, 2), gjoint[B:, :n_dx].contiguous().reshape(B, 1, 1, n_dx),
-                                  n_log, True, False, gx_planes=(0,))
+        g_x0f, _ = chain_backward(self.pDx, slice_saved(s_dx, 1, 2), *self._branch_grad(gjoint, B, B, 0, n_dx),
+                                  n_log, True, False, gx_planes=(0,), **self._join_out(gjoint))
         g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
         g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst)
         g_gin = g_gin.reshape(B, -1)
@@ -335,7 +387,7 @@ class AliStepper:
         fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
         x0d, n_log = self._planes(images, idx, cont, fam.d_tables)
         cx["x0d"], cx["n_log"] = x0d, n_log
-        cx["dx_pre"] = chain_forward(self.pDx, x0d, True, n_log, True)
+        cx["dx_pre"] = self._dx_forward(x0d, n_log, True)
 
     def _d_real_rest(self, cx):
         """D gradients on (x, E'(x)) (reference mnist.py:232-235); E' forward only."""
@@ -343,7 +395,8 @@ class AliStepper:
         x0d, n_log = cx["x0d"], cx["n_log"]
         x0e, _ = self._planes(images, idx, cont, fam.e_tables)
         ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
-        d_valid, sD = self._d_forward(x0d, n_log, ex, True, dx_pre=cx.pop("dx_pre"))
+        dx_pre, join = cx.pop("dx_pre")
+        d_valid, sD = self._d_forward(x0d, n_log, ex, True, dx_pre=dx_pre, join=join)
         l, gl = ops.bce_logits(d_valid, 1.0, self.loss_scale)
         cx["out"]["loss_d_real"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)

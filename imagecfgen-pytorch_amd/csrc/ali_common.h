@@ -19,23 +19,32 @@ inline int check_launch(const char* what) {
   return ALI_OK;
 }
 
-// Developer tuning knobs (scratch/ sweeps), read from the environment ONCE per process; 0 = use the built-in rule.
+// Developer tuning knobs (scratch/ sweeps, tests), read from the environment once per process and again on
+// ali_reload_tuning(); 0 = use the built-in rule.
 struct Tuning {
   int bm, bn, splitk;                       // ALI_BM / ALI_BN / ALI_SPLITK: force the gconv tile / split
   long long wgrad_small;                    // ALI_WGRAD_SMALL
   int wgrad_blocks, wgrad_scap;             // ALI_WGRAD_BLOCKS / ALI_WGRAD_SCAP
+  int no_order;                             // ALI_NO_ORDER=1: ignore AliEpilogue.tile_order (A/B measurements)
+  int wgrad_fold;                           // ALI_WGRAD_FOLD: most slabs a weight-gradient launch folds in-kernel (-1: default)
 };
-inline const Tuning& tuning() {
-  static const Tuning t = [] {
+inline Tuning read_tuning() {
+  {
     auto num = [](const char* name) -> long long { const char* e = getenv(name); return e ? atoll(e) : 0; };
     Tuning v;
     v.bm = (int)num("ALI_BM"); v.bn = (int)num("ALI_BN"); v.splitk = (int)num("ALI_SPLITK");
     v.wgrad_small = getenv("ALI_WGRAD_SMALL") ? num("ALI_WGRAD_SMALL") : -1;
     v.wgrad_blocks = (int)num("ALI_WGRAD_BLOCKS"); v.wgrad_scap = (int)num("ALI_WGRAD_SCAP");
+    v.no_order = (int)num("ALI_NO_ORDER");
+    v.wgrad_fold = getenv("ALI_WGRAD_FOLD") ? (int)num("ALI_WGRAD_FOLD") : -1;
     return v;
-  }();
+  }
+}
+inline Tuning& tuning_slot() {
+  static Tuning t = read_tuning();
   return t;
 }
+inline const Tuning& tuning() { return tuning_slot(); }
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;

@@ -30,6 +30,8 @@
 // Layers whose channel stride is not a multiple of 32 (first layers) take a simpler
 // generic loop.
 #include "ali_common.h"
+#include <algorithm>
+#include <vector>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -73,7 +75,10 @@ struct GDesc {
   int ldw, S;          // weight row stride (floats), kernel width (taps per kernel row)
   int nphase, splitk, kt_per_split;
   int ntile_m, ntile_n;     // m-tiles (all phases) and n-tiles of the launch
-  int tail_u0, tail_split;  // tail-split launches (tail_split > 1): see the kernel's block-index decoding
+  int lin1d;                // 1-D grid: tail-split and/or cost-ordered launches, see the kernel's block-index decoding
+  int tail_u0, tail_split;  // whole tiles first, then the left-over tiles cut tail_split ways along K
+  const int* order;         // AliEpilogue.tile_order (M-tile ids, longest k-loop first) or null
+  int ldi;                  // pixel pitch of the gathered operand (floats): Cin, or AliEpilogue.in_ld
   int f16;             // AliEpilogue.mfma_f16: fp16 operands on v_mfma_f32_32x32x16_f16 where the fast path applies
   const _Float16* in16;   // AliEpilogue.in16 / w16 / out16 (fp16 twins of in / w / out), or null
   const _Float16* w16;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   // the left-over tiles tail_split ways along K -- so the left-over costs every CU 1/tail_split of a tile instead of
   // costing a few CUs a whole one while the rest idle.
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nsplit = d.splitk;
-  if (d.tail_split > 1) {
+  if (d.lin1d) {
     int u = blockIdx.x;
     bz = 0;
     nsplit = 1;
@@ -144,8 +149,17 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
       bz = r - (r / d.tail_split) * d.tail_split;
       nsplit = d.tail_split;
     }
-    by = u / d.ntile_m;
-    bx = u - by * d.ntile_m;
+    if (d.order) {
+      // "Longest tile first" launches: dispatch slot u -> (rank in the cost-sorted M-tile list, n-tile), n fastest.
+      // The dispatcher deals workgroups round-robin over the CUs (measured: CU c of an all-resident grid holds slots
+      // c, c+256, c+512, ...), so every CU receives one tile of each cost quartile instead of e.g. four corner tiles.
+      const int rank = u / d.ntile_n;
+      by = u - rank * d.ntile_n;
+      bx = d.order[rank];
+    } else {
+      by = u / d.ntile_m;
+      bx = u - by * d.ntile_m;
+    }
   }
   int p = 0;
 #pragma unroll
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     decode(valid ? m : 0, img, qh, qw);
     aih[i] = qh * P.mult;
     aiw[i] = qw * P.mult;
-    aoff[i] = ((img * Hin + aih[i]) * Win + aiw[i]) * Cin;
+    aoff[i] = ((img * Hin + aih[i]) * Win + aiw[i]) * d.ldi;
     unsigned wbits = 0u, mk = 0u;
     for (int is = 0; is < P.ns; ++is)
       if ((unsigned)(aiw[i] + P.dw[is]) < (unsigned)Win) wbits |= 1u << is;
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
         const bool live = t < ntaps && ((tapmask >> t) & 1u);
         const int tv = s_tap[t < kMaxTaps ? t : 0];
         const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
-        s_live[t][0] = ((dh * Win + dw) * Cin) * 4;
+        s_live[t][0] = ((dh * Win + dw) * d.ldi) * 4;
         s_live[t][1] = live ? (wt * Cin) * 4 : (int)0xFFFFFF00u;
         s_live[t][2] = live ? (int)(1u << t) : 0;
         s_live[t][3] = 0;
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
       const int pos = __popc(tapmask & ((1u << t) - 1u));
       const int tv = s_tap[t];
       const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
-      s_live[pos][0] = ((dh * Win + dw) * Cin) * 4;
+      s_live[pos][0] = ((dh * Win + dw) * d.ldi) * 4;
       s_live[pos][1] = (wt * Cin) * 4;
       s_live[pos][2] = (int)(1u << t);
       s_live[pos][3] = 0;
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
         const int c = kflat - tap * Cin;
         const int tv = s_tap[tap];
         const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
-        const int doff = (dh * Win + dw) * Cin + c;
+        const int doff = (dh * Win + dw) * d.ldi + c;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
           const bool ok = kvalid && ((amask[i] >> tap) & 1u);
@@ -632,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
           const int c = kf - tap * Cin;
           const int tv = s_tap[tap];
           const int dh = (signed char)(tv & 0xff), dw = (signed char)((tv >> 8) & 0xff), wt = (tv >> 16) & 0xff;
-          const int doff = (dh * Win + dw) * Cin + c;
+          const int doff = (dh * Win + dw) * d.ldi + c;
 #pragma unroll
           for (int i = 0; i < AP; ++i) {
             const bool ok = kvalid && ((amask[i] >> tap) & 1u);
@@ -946,6 +960,32 @@ static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps) {
   return tiles;
 }
 
+// k-loop length (live taps) of every M-tile of a launch whose rows are ordered (pixel, image): the taps that fall
+// outside the input are skipped tile-wide, so edge tiles of padded / transposed convolutions are short.  Mirrors the
+// kernel's amask / tapmask computation.  Returns false when some phase is not pixel-major (tiles mix positions).
+static bool tile_costs(const GDesc& d, int bm, std::vector<int>& cost) {
+  cost.clear();
+  for (int p = 0; p < d.nphase; ++p) {
+    const Phase& P = d.ph[p];
+    if (!P.pixmajor) return false;
+    const int nt = (P.M + bm - 1) / bm;
+    for (int ti = 0; ti < nt; ++ti) {
+      const int m_lo = ti * bm, m_hi = std::min(P.M, m_lo + bm) - 1;
+      unsigned mask = 0u;
+      for (int pix = m_lo / d.B; pix <= m_hi / d.B; ++pix) {
+        const int qh = pix / P.Wq, qw = pix - qh * P.Wq;
+        unsigned wbits = 0u;
+        for (int is = 0; is < P.ns; ++is)
+          if ((unsigned)(qw * P.mult + P.dw[is]) < (unsigned)d.Win) wbits |= 1u << is;
+        for (int ir = 0; ir < P.nr; ++ir)
+          if ((unsigned)(qh * P.mult + P.dh[ir]) < (unsigned)d.Hin) mask |= wbits << (ir * P.ns);
+      }
+      cost.push_back(__builtin_popcount(mask));
+    }
+  }
+  return true;
+}
+
 static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec, bool dense_k) {
   TileCfg tc;
   int max_taps = 0;
@@ -966,8 +1006,18 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     if (!ok) { set_error("gconv: bad fused BatchNorm epilogue (see AliEpilogue / ali_conv_mtiles)"); return ALI_ERR_BAD_ARG; }
   }
   const int ntile_n = (d.Cout + tc.bn - 1) / tc.bn;
+  d.ldi = d.Cin;
+  if (d.ep.in_ld > 0 || d.ep.out_ld > 0) {     // operands that are column ranges of wider row-major buffers
+    if ((d.ep.in_ld > 0 && (d.ep.in_ld < d.Cin || (vec && d.ep.in_ld % 4))) ||
+        (d.ep.out_ld > 0 && (d.ep.out_ld < d.Cout || d.ep.bn_part))) {
+      set_error("gconv: bad in_ld / out_ld (>= the channel count, in_ld % 4 == 0 for vector gathers, no out_ld with fused BatchNorm)");
+      return ALI_ERR_BAD_ARG;
+    }
+    if (d.ep.in_ld > 0) d.ldi = d.ep.in_ld;
+    if (d.ep.out_ld > 0) d.ldo = d.ep.out_ld;
+  }
   d.out_elems = (long long)d.B * d.Hout * d.Wout * d.ldo;
-  const long long in_elems = (long long)d.B * d.Hin * d.Win * d.Cin;
+  const long long in_elems = ((long long)d.B * d.Hin * d.Win - 1) * d.ldi + d.Cin;
   const long long w_elems = (long long)d.Cout * d.ldw;
   if (d.out_elems >= (1LL << 31) || in_elems >= (1LL << 30) || w_elems >= (1LL << 29)) {
     set_error("gconv: tensor too large for 32-bit byte offsets");
@@ -1024,10 +1074,17 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
       d.tail_u0 = (int)(blocks - R);
     }
   }
+  // cost-ordered dispatch (AliEpilogue.tile_order / ali_conv_tile_order): only launches whose blocks each own a whole
+  // k-loop or a tail-split share of one
+  d.order = nullptr;
+  if (d.ep.tile_order && uni && S == 1 && d.ep.tile_order_n == tiles && tuning().no_order == 0)
+    d.order = reinterpret_cast<const int*>(d.ep.tile_order);
+  d.lin1d = (d.tail_split > 1 || d.order) ? 1 : 0;
+  if (d.tail_split == 1) d.tail_u0 = (int)blocks;
   d.ctr = reinterpret_cast<int*>(ws);
   d.ws = reinterpret_cast<float*>(ws_payload(ws));
   dim3 grid(tiles, ntile_n, S), block(256);
-  if (d.tail_split > 1) grid = dim3(d.tail_u0 + (int)(blocks - d.tail_u0) * d.tail_split, 1, 1);
+  if (d.lin1d) grid = dim3(d.tail_u0 + (int)(blocks - d.tail_u0) * d.tail_split, 1, 1);
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
   const bool f16 = d.f16 && uni;
   const bool op16 = f16 && d.in16 && d.w16 && (d.Cin % 64) == 0;
@@ -1073,6 +1130,7 @@ using namespace ali;
 
 extern "C" const char* ali_last_error(void) { return ali::get_error(); }
 extern "C" int ali_version(void) { return 1; }
+extern "C" void ali_reload_tuning(void) { ali::tuning_slot() = ali::read_tuning(); }
 
 extern "C" size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which) {
   if (!geom_ok(g)) return 0;
@@ -1264,6 +1322,31 @@ extern "C" int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t 
   if (tiles < 0) return 0;
   if (tile_rows) *tile_rows = tc.bm;
   if (pixel_major) *pixel_major = d.ph[0].pixmajor;
+  return tiles;
+}
+
+extern "C" int32_t ali_conv_tile_order(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* order,
+                                       int32_t cap) {
+  if (!geom_ok(g) || (which != 0 && which != 1) || !order) return 0;
+  if (which == 0 && conv_first_ok(g, nullptr, mfma_f16 != 0)) return 0;
+  GDesc d;
+  memset(&d, 0, sizeof(d));
+  d.f16 = mfma_f16 != 0;
+  bool vec;
+  if (which == 0) { setup_fwd(g, d); vec = (g->C % 4) == 0; }
+  else { if (!setup_bwd_data(g, d)) return 0; vec = (g->K % 4) == 0; }
+  if (!vec || (d.Cin % BK) != 0) return 0;          // only the uniform-tap loop skips dead taps tile-wide
+  TileCfg tc;
+  int max_taps = 0;
+  const int tiles = plan_tiles(d, vec, tc, max_taps);
+  if (tiles <= 0 || tiles > cap) return 0;
+  std::vector<int> cost;
+  if (!tile_costs(d, tc.bm, cost) || (int)cost.size() != tiles) return 0;
+  if (*std::max_element(cost.begin(), cost.end()) == *std::min_element(cost.begin(), cost.end())) return 0;
+  std::vector<int> idx(tiles);
+  for (int i = 0; i < tiles; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  for (int i = 0; i < tiles; ++i) order[i] = idx[i];
   return tiles;
 }
 

@@ -35,6 +35,8 @@ struct WDesc {
   const int* pixtab;  // optional [npix][2] (ali_wgrad_pixtab)
   const _Float16* x16;   // fp16 twins of x / dy (same shapes), or null: the F16 == 2 kernels read these
   const _Float16* dy16;
+  int ldd;            // floats between consecutive pixels of dy (Cd, or more when dy is a column range of wider rows)
+  int* ctr;           // split-K arrival counters (one per weight tile, zero between launches): fold in the kernel
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VECA, bool VECB>
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   };
   auto load_b = [&](int pix0, int j) {
     const int pix = pix0 + brow0 + j * BROWS;
-    const unsigned off = (b_ok && pix < pix_end) ? (unsigned)(pix * d.Cd + nB) * 4u : OOB;
+    const unsigned off = (b_ok && pix < pix_end) ? (unsigned)(pix * d.ldd + nB) * 4u : OOB;
     rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0));
   };
   auto store_tile = [&](int buf) {
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
           for (int r = 0; r < BROWS8; ++r) sum += red[r * BN + t];
           const int n = n0 + t;
           if (n < d.Cd_log) {
-            if (d.splitk > 1) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
+            if (d.splitk > 1) __hip_atomic_store(&d.dbws[(long long)blockIdx.z * d.Cd + n], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else d.db[n] = sum;
           }
         }
@@ -618,6 +620,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   }
 
   const bool partial = d.splitk > 1;
+  const bool fold = partial && d.ctr != nullptr;   // slabs are summed by the block that arrives last at the tile (below)
   if (do_db && F16 != 2) {   // fold the per-thread column sums over the BROWS row lanes (fixed order), then one store per column
     __syncthreads();
     float* red = &As[0][0];                       // BROWS x BN floats <= tile size
@@ -628,29 +631,121 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
       for (int r = 0; r < BROWS; ++r) sum += red[r * BN + t];
       const int n = n0 + t;
       if (n < d.Cd_log) {
-        if (partial) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
+        if (partial) __hip_atomic_store(&d.dbws[(long long)blockIdx.z * d.Cd + n], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else d.db[n] = sum;
       }
     }
   }
+  if (partial) {
+    // raw partial tile -> this split's slab (device-scope stores: see the split-K hand-off in gconv.hip)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 32 + (lane & 31);
-    if (n >= (partial ? d.Cd : d.Cd_log)) continue;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 32 + (lane & 31);
+      if (n >= d.Cd) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < d.Mtot)
+            __hip_atomic_store(&d.ws[(long long)blockIdx.z * d.slab + (long long)m * d.Cd + n], acc[i][j][r],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (!fold) return;            // the stand-alone reduction kernels sum the slabs
+    // Last-arriving block of the tile sums the S slabs in slab order (deterministic whichever block that is) and
+    // writes the parameter layout: same store / counter / load discipline as gconv.hip's split-K (sc1 stores, wait,
+    // barrier, agent-scope RMW, sc1 loads), counter left at zero for the next launch.
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (t == 0) {
+      int* c = d.ctr + (blockIdx.y * gridDim.x + blockIdx.x);
+      const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = arrived == d.splitk - 1;
+      if (s_last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const unsigned slab_bytes = (unsigned)(d.slab * 4);
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)d.ws, 0, (unsigned)(((long long)d.splitk * d.slab + (long long)d.splitk * d.Cd) * 4), 0x00020000);
+    constexpr int kSc1 = 16;      // cache policy: device scope
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float v = acc[i][j][r];
-        if (partial) {
-          const int m = m0 + row;
-          if (m < d.Mtot) d.ws[(long long)blockIdx.z * d.slab + (long long)m * d.Cd + n] = v;
-        } else {
-          const long long off = s_rowdst[row];
-          if (off >= 0) d.dst[off + n * d.s_dc] = v;
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        unsigned voff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          voff[r] = (n < d.Cd && m < d.Mtot) ? (unsigned)(m * d.Cd + n) * 4u : OOB;
         }
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        int sl0 = 0;
+        for (; sl0 + 4 <= d.splitk; sl0 += 4) {      // 4 slabs x 16 rows requested before the first is consumed
+          float tmp[4][16];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned soff = (unsigned)(sl0 + u) * slab_bytes;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              tmp[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, (int)voff[r], (int)soff, kSc1));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += tmp[u][r];
+        }
+        for (; sl0 < d.splitk; ++sl0) {
+          const unsigned soff = (unsigned)sl0 * slab_bytes;
+          float tmp[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tmp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, (int)voff[r], (int)soff, kSc1));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += tmp[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = v[r];
       }
+    }
+    if (do_db && t < BN && n0 + t < d.Cd_log) {     // the bias gradient's slabs [S][Cd] sit behind the weight slabs
+      const unsigned base = (unsigned)((long long)d.splitk * d.slab * 4);
+      float sum = 0.f;
+      for (int sl = 0; sl < d.splitk; ++sl)
+        sum += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                   rws, (int)((unsigned)(sl * d.Cd + n0 + t) * 4u), (int)base, kSc1));
+      d.db[n0 + t] = sum;
+    }
+  }
+  // Final tile -> parameter layout dst[dc*s_dc + gc*s_gc + tap*s_tap], transposed through LDS one 32x32 MFMA tile per
+  // wave at a time (the operand tiles are dead): a lane then walks the gathered channels of ONE dense channel, whose
+  // destinations are s_gc floats apart (contiguous for 1x1 kernels) instead of a whole filter apart.
+  __syncthreads();
+  float* tr = &As[0][0] + wave * (32 * 33);
+  static_assert(4 * 32 * 33 <= 2 * WBK2 * LDA, "transposition scratch fits the A tiles");
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tr[(lane & 31) * 33 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = acc[i][j][r];
+      __syncthreads();
+      const long long off = s_rowdst[wm * WM + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int nl = 2 * k + (lane >> 5);
+        const int n = n0 + wn * WN + j * 32 + nl;
+        const float v = tr[nl * 33 + (lane & 31)];
+        if (off >= 0 && n < d.Cd_log) d.dst[off + n * d.s_dc] = v;
+      }
+      __syncthreads();
     }
   }
 }
@@ -766,7 +861,7 @@ using namespace ali;
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
                                    int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
                                    const int32_t* pixtab, int32_t mfma_f16, const void* x16, const void* dy16,
-                                   void* ws, size_t ws_bytes, ali_stream_t stream_) {
+                                   int32_t dy_ld, void* ws, size_t ws_bytes, ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
     return ALI_ERR_BAD_ARG;
@@ -785,8 +880,15 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   d.Mtot = g->R * g->S * g->C;
   d.npix = g->B * g->P * g->Q;
   const bool veca = (g->C % 4) == 0, vecb = (g->K % 4) == 0;
-  const long long x_elems = (long long)g->B * g->H * g->W * g->C, dy_elems = (long long)g->B * g->P * g->Q * g->K;
+  d.ldd = dy_ld > 0 ? dy_ld : g->K;
+  const long long x_elems = (long long)g->B * g->H * g->W * g->C;
+  const long long dy_elems = ((long long)g->B * g->P * g->Q - 1) * d.ldd + g->K;
+  if (d.ldd != g->K && (d.ldd < g->K || (d.ldd % 4) || !veca || !vecb)) {
+    set_error("ali_conv_bwd_weight: dy_ld needs the vector kernels (channel counts % 4 == 0) and dy_ld >= K, % 4 == 0");
+    return ALI_ERR_BAD_ARG;
+  }
   const bool fast = veca && vecb && x_elems < (1LL << 30) && dy_elems < (1LL << 30) && d.npix < (1 << 24);
+  if (!fast && d.ldd != g->K) { set_error("ali_conv_bwd_weight: dy_ld on a tensor too large for the vector kernels"); return ALI_ERR_BAD_ARG; }
   int bn = g->K > 64 ? 128 : (g->K > 32 ? 64 : 32);
   int bm = 128;
   if (fast) {
@@ -828,13 +930,20 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   d.db = fast ? db : nullptr;
   d.slab = (long long)d.Mtot * g->K + kSlabPad;
   d.dbws = d.ws + (size_t)S * d.slab;
+  // few slabs per tile: the block that finishes a tile last sums them itself (no second launch); long folds (first
+  // layers of the spectrogram models: hundreds of slabs for a handful of tiles) keep the wide stand-alone reduction
+  int fold_cap = 64;
+  if (tuning().wgrad_fold >= 0) fold_cap = tuning().wgrad_fold;
+  if (fast && S > 1 && S <= fold_cap && blocks <= (long long)(kWsReserved / sizeof(int)) &&
+      ((size_t)S * d.slab + (size_t)S * g->K) * sizeof(float) < (1ull << 32))
+    d.ctr = reinterpret_cast<int*>(ws_all);
   dim3 grid(tiles_m, tiles_n, S), block(256);
   if (fast) {
     const unsigned xb = (unsigned)(x_elems * 4), yb = (unsigned)(dy_elems * 4);
     // the table packs positions as 16-bit fields: maps up to 8191 x 8191
     d.pixtab = (pixtab && g->H < 0x2000 && g->W < 0x2000 && g->pad < 0x2000) ? pixtab : nullptr;
     const bool f16 = mfma_f16 && d.pixtab;
-    const bool mem16 = f16 && x16 && dy16 && (g->C % 8) == 0 && (g->K % 8) == 0 && bn >= 64;
+    const bool mem16 = f16 && x16 && dy16 && (g->C % 8) == 0 && (g->K % 8) == 0 && bn >= 64 && d.ldd == g->K;
     d.x16 = mem16 ? reinterpret_cast<const _Float16*>(x16) : nullptr;
     d.dy16 = mem16 ? reinterpret_cast<const _Float16*>(dy16) : nullptr;
 #define FLAUNCH1(BM_, BN_, WMM, WNN)                                                                              \
@@ -869,7 +978,7 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   }
   int rc = check_launch("wgrad_kernel");
   if (rc) return rc;
-  if (S > 1) {
+  if (S > 1 && !d.ctr) {
     const long long total = (long long)d.Mtot * g->K;
     const int T = g->R * g->S;
     if (fast && T <= kRedRows) {

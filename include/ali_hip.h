@@ -100,6 +100,15 @@ typedef struct {
   const void* in16;
   const void* w16;
   void* out16;
+  /* Dispatch order of the launch's M-tiles (device int32[tile_order_n], from ali_conv_tile_order; NULL = natural
+   * order).  Ignored unless tile_order_n equals the launch's M-tile count and every block owns a whole k-loop. */
+  const int32_t* tile_order;
+  int32_t tile_order_n;
+  /* Operands that are column ranges of wider row-major buffers (the Discriminator's joint [dx | dz] rows,
+   * mnist.py:152-154): in_ld = floats between consecutive pixels of the gathered operand (its fp16 twin alike),
+   * out_ld = the same for the output (and dact_y, out16).  0 = dense.  Not with the fused BatchNorm modes. */
+  int32_t in_ld;
+  int32_t out_ld;
 } AliEpilogue;
 
 /* ---- implicit-GEMM convolutions (fp32 MFMA v_mfma_f32_32x32x2_f32) -------
@@ -122,6 +131,13 @@ size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which /*0 fwd,1 bw
  * B/groups * P*Q % tile_rows == 0). */
 int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* tile_rows,
                         int32_t* pixel_major);
+/* Host-side: the M-tile ids of the launch ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) makes for g, sorted
+ * by k-loop length, longest first (edge tiles of padded / strided-transposed convolutions skip the taps that fall
+ * outside the input).  The workgroup dispatcher deals blocks round-robin over the CUs, so dispatching in this order
+ * gives every CU the same mix of long and short tiles.  Writes at most cap ids to order (host memory) and returns their
+ * number; 0 when all tiles cost the same or the launch cannot use an order.  Upload once per geometry and pass as
+ * AliEpilogue.tile_order. */
+int32_t ali_conv_tile_order(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* order, int32_t cap);
 /* 1 if the launch ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) makes for g with mfma_f16 = 1 runs on
  * fp16 MFMA, i.e. writes AliEpilogue.out16. */
 int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which);
@@ -136,6 +152,8 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                         int32_t mfma_f16 /* as AliEpilogue.mfma_f16 (needs pixtab); accumulation and slabs stay fp32 */,
                         const void* x16, const void* dy16 /* optional fp16 twins of x / dy (AliEpilogue.out16 of the
                                                              launches that produced them): read instead of x / dy */,
+                        int32_t dy_ld /* floats between consecutive pixels of dy; 0 = K (dense).  > K: dy is a column
+                                         range of wider rows (AliEpilogue.in_ld / out_ld); twins are then not read */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
 /* Per-geometry table for ali_conv_bwd_weight: entry i (2 x int32) of output pixel i = (b,p,q) holds the byte offset of
  * x[b, p*stride, q*stride, 0] and the packed pair (p*stride, q*stride); the kernel adds its tap's (r-pad, s-pad).  With it the kernel's gather
@@ -309,6 +327,9 @@ int ali_spect_post(const float* y, int32_t B, int32_t T, int32_t F, const float*
 
 const char* ali_last_error(void);
 int ali_version(void);
+/* Re-read the developer tuning variables (ALI_SPLITK, ALI_NO_ORDER, ...: csrc/ali_common.h) from the environment;
+ * they are otherwise read once per process.  Tests and sweeps only. */
+void ali_reload_tuning(void);
 
 #ifdef __cplusplus
 }

@@ -281,11 +281,88 @@ def test_spectrogram_front_end_vs_torch_stft(n_fft, win, hop, pad, L):
     assert (got_img - img)[sel].abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", [
+    ("dgrad", 512, 128, 8, 256, 4, 2, 0), ("dgrad", 512, 256, 7, 512, 3, 2, 0), ("dgrad", 128, 64, 11, 128, 4, 1, 0),
+    ("fwd", 512, 128, 13, 256, 3, 2, 1), ("fwd", 192, 64, 14, 128, 4, 2, 1), ("dgrad", 576, 128, 13, 256, 3, 2, 1)])
+def test_cost_ordered_dispatch_is_a_pure_reordering(kind, B, C, H, K, R, stride, pad):
+    """ali_conv_tile_order: launches whose M-tiles have different k-loop lengths (padding / strided transposed taps
+    skipped tile-wide) dispatch the long tiles first.  The table is a permutation sorted by the number of live taps,
+    and the launch computes bit-identical results with and without it (incl. tail-split grids and the fused
+    BatchNorm partial sums, whose slots are indexed by the logical tile)."""
+    import ctypes
+    import os
+    import ali_hip
+    ops = _ops()
+    P = (H + 2 * pad - R) // stride + 1
+    geom = ops.geom(B, H, H, C, P, P, K, R, R, stride, pad)
+    which = 0 if kind == "fwd" else 1
+    buf = (ctypes.c_int32 * 65536)()
+    n = ali_hip.load().ali_conv_tile_order(ctypes.byref(geom), which, 0, ctypes.cast(buf, ctypes.c_void_p), 65536)
+    tiles, rows, pm = ops.conv_mtiles(geom, which)
+    assert n == tiles and pm and sorted(buf[:n]) == list(range(n))
+    # live taps of a tile's pixel position, recomputed here
+    def taps(tile):
+        if kind == "fwd":
+            pix = tile * rows // B
+            qh, qw = divmod(pix, P)
+            vh = sum(0 <= qh * stride - pad + r < H for r in range(R))
+            vw = sum(0 <= qw * stride - pad + r < H for r in range(R))
+            return vh * vw
+        # data gradient: phases (oh % stride, ow % stride) in order, each a (pixel, image) raster of its sub-grid
+        t0 = 0
+        for ph in range(stride):
+            for pw in range(stride):
+                Hq, Wq = (H - ph + stride - 1) // stride, (H - pw + stride - 1) // stride
+                nt = (B * Hq * Wq + rows - 1) // rows
+                if tile < t0 + nt:
+                    pix = (tile - t0) * rows // B
+                    qh, qw = divmod(pix, Wq)
+                    oh, ow = ph + qh * stride, pw + qw * stride
+                    vh = sum((oh + pad - r) % stride == 0 and 0 <= (oh + pad - r) // stride < P for r in range(R))
+                    vw = sum((ow + pad - r) % stride == 0 and 0 <= (ow + pad - r) // stride < P for r in range(R))
+                    return vh * vw
+                t0 += nt
+        raise AssertionError(tile)
+    if B % rows == 0:
+        costs = [taps(t) for t in buf[:n]]
+        assert costs == sorted(costs, reverse=True) and costs[0] > costs[-1]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    T = R * R
+    if kind == "fwd":
+        a = torch.randn(B, H, H, C, device="cuda", generator=g)
+        w = torch.randn(K, T, C, device="cuda", generator=g) / (C * T) ** 0.5
+        out_shape, run = (B, P, P, K), ops.conv_fwd
+    else:
+        a = torch.randn(B, P, P, K, device="cuda", generator=g)
+        w = torch.randn(C, T, K, device="cuda", generator=g) / (K * T) ** 0.5
+        out_shape, run = (B, H, H, C), ops.conv_bwd_data
+    outs = []
+    try:
+        for off in ("0", "1"):
+            os.environ["ALI_NO_ORDER"] = off
+            ali_hip.load().ali_reload_tuning()
+            y = torch.full(out_shape, float("nan"), device="cuda")
+            slots = ops.conv_mtiles(geom, which)[0]
+            part = torch.zeros(2 * out_shape[3] * slots, device="cuda")
+            if kind == "fwd":
+                ep = ops.epilogue(act=ops.ACT_LEAKY, slope=0.1, bn_fwd=(part, 1, None))
+            else:
+                ep = ops.epilogue()
+            run(geom, a, w, y, ep)
+            outs.append((y, part))
+    finally:
+        os.environ.pop("ALI_NO_ORDER", None)
+        ali_hip.load().ali_reload_tuning()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.isnan(outs[0][0]).any()
+
+
 def test_splitk_last_block_fold_stress():
     """The in-kernel split-K fold (slabs written and read with device-scope accesses, per-tile arrival counters) under
     back-to-back launches that reuse the same slabs with different data: a stale slab or a counter left non-zero
     would show up as an O(1) error.  600 launches, three shapes, alternating inputs."""
     import os
+    import ali_hip
     ops = _ops()
     g = torch.Generator().manual_seed(12)
     old = os.environ.get("ALI_SPLITK")
@@ -295,8 +372,10 @@ def test_splitk_last_block_fold_stress():
             w = (torch.randn(K, 1, C, generator=g) * 0.05).cuda()
             geom = ops.geom(B, 1, 1, C, 1, 1, K, 1, 1, 1, 0)
             os.environ["ALI_SPLITK"] = "1"
+            ali_hip.load().ali_reload_tuning()
             refs = [ops.conv_fwd(geom, x, w, torch.empty(B, 1, 1, K, device="cuda"), ops.epilogue()).clone() for x in xs]
             os.environ["ALI_SPLITK"] = str(S)
+            ali_hip.load().ali_reload_tuning()
             y = torch.empty(B, 1, 1, K, device="cuda")
             worst = torch.zeros((), device="cuda")
             for it in range(200):
@@ -309,6 +388,7 @@ def test_splitk_last_block_fold_stress():
             os.environ.pop("ALI_SPLITK", None)
         else:
             os.environ["ALI_SPLITK"] = old
+        ali_hip.load().ali_reload_tuning()
 
 
 @pytest.mark.parametrize("B,H,W,n_rows,Cg,Cx", [(37, 28, 28, 10, 8, 8), (5, 128, 128, 3, 2, 4), (600, 28, 28, 10, 1, 8),

@@ -25,6 +25,32 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.ali_version() >= 1
 
 
+def test_tile_order_is_host_side_and_sorted_by_live_taps():
+    """ali_conv_tile_order runs on the host (no GPU): a permutation of the M-tiles of MNIST D's 256 -> 128 4x4 stride-2
+    data gradient (mnist.py:120) with the 16 interior pixel positions (4 live taps) first and the corners last; layers
+    whose tiles all cost the same report 0."""
+    import ctypes
+    import ali_hip
+    from ali_hip import ops
+    lib = ali_hip.load()
+    buf = (ctypes.c_int32 * 4096)()
+    g = ops.geom(512, 8, 8, 128, 3, 3, 256, 4, 4, 2, 0)
+    n = lib.ali_conv_tile_order(ctypes.byref(g), 1, 0, ctypes.cast(buf, ctypes.c_void_p), 4096)
+    assert n == 512 and sorted(buf[:n]) == list(range(512))       # 4 phases x 16 pixels x 8 tiles of 64 images
+
+    def live(tile):     # phase (ph, pw), pixel (qh, qw) of the phase's 4 x 4 sub-grid -> taps inside the 3 x 3 input
+        ph, rem = divmod(tile, 128)
+        qh, qw = divmod(rem // 8, 4)
+        oh, ow = (ph // 2) + 2 * qh, (ph % 2) + 2 * qw
+        cnt = lambda o: sum((o - r) % 2 == 0 and 0 <= (o - r) // 2 < 3 for r in range(4))      # noqa: E731
+        return cnt(oh) * cnt(ow)
+    costs = [live(t) for t in buf[:n]]
+    assert costs == sorted(costs, reverse=True) and costs[:128] == [4] * 128 and costs[-128:] == [1] * 128
+    g1 = ops.geom(512, 1, 1, 1024, 1, 1, 1024, 1, 1, 1, 0)
+    assert lib.ali_conv_tile_order(ctypes.byref(g1), 0, 0, ctypes.cast(buf, ctypes.c_void_p), 4096) == 0
+    assert lib.ali_conv_tile_order(ctypes.byref(g), 1, 0, ctypes.cast(buf, ctypes.c_void_p), 100) == 0   # cap too small
+
+
 def test_product_mnist_modules_match_oracle_on_cpu():
     import image_scms.mnist as pm
     torch.manual_seed(5)
