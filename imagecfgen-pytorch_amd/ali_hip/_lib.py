@@ -30,6 +30,13 @@ class AliEpilogue(Structure):
                 ("tile_order", c_void_p), ("tile_order_n", c_int32), ("in_ld", c_int32), ("out_ld", c_int32)]
 
 
+class AliWgradFold(Structure):
+    _fields_ = [("ws", c_void_p), ("dst", c_void_p), ("dbws", c_void_p), ("db", c_void_p),
+                ("slab", c_int64), ("s_dc", c_int64), ("s_gc", c_int64), ("s_tap", c_int64),
+                ("S", c_int32), ("Mtot", c_int32), ("Cg", c_int32), ("Cd", c_int32), ("Cg_log", c_int32),
+                ("Cd_log", c_int32), ("T", c_int32), ("reserved", c_int32), ("ws_used", c_uint64)]
+
+
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol include/ali_hip.h declares
@@ -43,8 +50,9 @@ SIGNATURES = {
     "ali_conv_bwd_data": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue),
                                     c_void_p, c_size_t, c_void_p]),
     "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
-                                      c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
-                                      c_size_t, c_void_p]),
+                                      c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
+                                      POINTER(AliWgradFold), c_void_p, c_size_t, c_void_p]),
+    "ali_wgrad_fold_multi": (c_int32, [c_int32, POINTER(AliWgradFold), c_void_p]),
     "ali_wgrad_pixtab": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p]),
     "ali_pack_weights": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
                                    c_void_p]),

@@ -451,7 +451,7 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
 
 
 def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True,
-                   grad_dst=None, gx_planes=None, gy_ld: int = 0, gy_pre: bool = False, in_act=None):
+                   grad_dst=None, gx_planes=None, gy_ld: int = 0, gy_pre: bool = False, in_act=None, fold=None):
     """Returns (gx or None, {param tensor id -> grad}).  ``grad_dst`` optionally maps id(param) to a
     preallocated destination (a view of a flat gradient buffer) that the kernels write directly.
     ``gx_planes`` (hand-scheduled step only): instead of the full input gradient return only these input
@@ -460,7 +460,9 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
     ``gy_ld`` > 0 (needs ``join_ok``): ``gy`` is a column range (strided view, rows ``gy_ld`` floats apart) of a wider
     buffer; ``gy_pre``: it already is the gradient of the last stage's PRE-activation.  ``in_act`` = (act, slope) of the
     activation that produced this chain's input ``x`` (the ends of the chains whose outputs were joined): the returned
-    gradient is then the one of their pre-activations, computed by the first stage's data-gradient epilogue."""
+    gradient is then the one of their pre-activations, computed by the first stage's data-gradient epilogue.
+    ``fold`` (ops.FoldQueue): the weight-gradient launches leave their slab reductions to ``fold.flush()`` -- the
+    parameter gradients are complete only after the caller has flushed."""
     grads = {}
     grad_dst = grad_dst or {}
     n = len(plan.stages)
@@ -511,7 +513,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                                  m.kernel_size[0], m.kernel_size[1], m.padding[0])
             elif st.kind == "conv":
                 T = m.kernel_size[0] * m.kernel_size[1]
-                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1, db=fused_db, dy_ld=ld)
+                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1, db=fused_db, dy_ld=ld, defer=fold)
             elif _is_tconv1(st, Cp):
                 T = m.kernel_size[0] * m.kernel_size[1]
                 ops.tconv1_wgrad(sv.t, g_pre, 1, 1, dw, T, 1, 0, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1],
@@ -519,16 +521,16 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             elif st.kind == "convT":
                 T = m.kernel_size[0] * m.kernel_size[1]
                 # gathered operand = convT output-grad (channels K), dense = convT input (channels Cp)
-                ops.conv_bwd_weight(g, g_pre, sv.t, dw, K, c_in_log, K * T, T, 1)
+                ops.conv_bwd_weight(g, g_pre, sv.t, dw, K, c_in_log, K * T, T, 1, defer=fold)
             else:
                 O, I = m.weight.shape
                 Cc, hh, ww = st.unflat if st.unflat else (O, 1, 1)
                 T = hh * ww
                 if T == 1:
-                    ops.conv_bwd_weight(g, sv.t, g_pre, dw, I, O, I, 1, 0)
+                    ops.conv_bwd_weight(g, sv.t, g_pre, dw, I, O, I, 1, 0, defer=fold)
                 else:
                     tmp = torch.empty(O, I, device=dw.device)   # rows in n' = t*C + co order
-                    ops.conv_bwd_weight(g, sv.t, g_pre, tmp, I, O, I, 1, 0)
+                    ops.conv_bwd_weight(g, sv.t, g_pre, tmp, I, O, I, 1, 0)      # (re-packed right away: not deferred)
                     ops.pack_weights(tmp, dw, Cc, T, I, I, I, Cc * I, 1)
             grads[id(m.weight)] = dw
         # ---- data gradient, folded with what sits between y_{i-1} and this conv

@@ -320,9 +320,41 @@ def wgrad_pixtab(g: AliConvGeom, device):
     return tab
 
 
-def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap, db=None, dy_ld=0):
+class FoldQueue:
+    """Deferred slab reductions of the weight-gradient launches of one backward pass (include/ali_hip.h: AliWgradFold):
+    ``conv_bwd_weight(..., defer=queue)`` gives each launch its own region of the queue's arena and skips the second
+    (reduction) launch; ``flush()`` folds them all at once.  The arena is allocated once per device and shared (one
+    backward pass is in flight at a time; captured graphs keep pointing into it)."""
+    _arena = {}
+    arena_bytes = 512 << 20
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+        self.off = 0
+
+    def arena(self):
+        a = FoldQueue._arena.get(self.device.index)
+        if a is None or a.numel() * 4 < FoldQueue.arena_bytes:
+            a = FoldQueue._arena[self.device.index] = torch.zeros(FoldQueue.arena_bytes // 4, dtype=torch.float32,
+                                                                   device=self.device)
+        return a
+
+    def flush(self):
+        if self.jobs:
+            arr = (_lib.AliWgradFold * len(self.jobs))(*self.jobs)
+            n = len(self.jobs)
+
+            def go():
+                _lib.check(_lib.load().ali_wgrad_fold_multi(n, arr, _stream()), "ali_wgrad_fold_multi")
+            _launch("wgrad_fold", 0.0, (0,) * 10, go)
+        self.jobs, self.off = [], 0
+
+
+def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap, db=None, dy_ld=0, defer=None):
     """``db`` (optional, [cd_log]): also produce the column sums of ``dy`` (Conv2d bias gradient) in the same launch.
-    ``dy_ld`` > 0: ``dy`` is a column range (a strided view) of rows that are ``dy_ld`` floats apart."""
+    ``dy_ld`` > 0: ``dy`` is a column range (a strided view) of rows that are ``dy_ld`` floats apart.
+    ``defer`` (FoldQueue): leave the slab reduction of a split launch to ``defer.flush()``."""
     lib = _lib.load()
     ws = workspace(x.device)
     tab = wgrad_pixtab(g, x.device) if (g.C % 4 == 0 and g.K % 4 == 0) else None
@@ -330,6 +362,12 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
     x16, dy16 = (shadow16(x), shadow16(dy)) if (f16 and not dy_ld) else (None, None)
     if x16 is None or dy16 is None:
         x16 = dy16 = None
+    ws_ptr, ws_n, job = ws.data_ptr(), ws.numel(), None
+    if defer is not None:
+        arena = defer.arena()
+        left = arena.numel() * 4 - defer.off
+        if left >= (32 << 20):                    # a region of its own (else: the shared workspace, immediate fold)
+            ws_ptr, ws_n, job = arena.data_ptr() + defer.off, left, _lib.AliWgradFold()
 
     def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _ptr(dy) if dy_ld else _chk(dy, "dy"),
@@ -338,8 +376,12 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
                                            None if tab is None else c_void_p(tab.data_ptr()), f16,
                                            None if x16 is None else c_void_p(x16.data_ptr()),
                                            None if dy16 is None else c_void_p(dy16.data_ptr()), dy_ld,
-                                           c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_weight")
+                                           None if job is None else byref(job),
+                                           c_void_p(ws_ptr), ws_n, _stream()), "ali_conv_bwd_weight")
     _launch("wgrad", *_geom_cost(g), go)
+    if job is not None and job.S > 0:
+        defer.jobs.append(job)
+        defer.off += (int(job.ws_used) + 255) // 256 * 256
     return dst
 
 

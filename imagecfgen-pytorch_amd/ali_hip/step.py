@@ -191,6 +191,9 @@ class AliStepper:
                       and f0.kind == "conv" and [k for k, _ in f0.pre] == ["drop"]
                       and f0.mod.in_channels == lx.mod.out_channels + lz.mod.out_channels
                       and tuple(f0.mod.kernel_size) == (1, 1))
+        self._fold = ops.FoldQueue(self.opt_d.flat.device) if self.opt_d.flat.is_cuda else None
+        if self._fold is not None:
+            self._fold.arena()
         self._join_act = (lx.act, lx.slope)
         self._join_skip = sum(1 for pl in (self.pDx, self.pDz) for st in pl.stages if any(k == "drop" for k, _ in st.pre))
 
@@ -273,18 +276,21 @@ class AliStepper:
         s_dx, s_dz, s_dxz, n_dx, n_log = saved
         B = glogit.shape[0]
         dst = self.opt_d.grad_views if need_params else None
+        fold = self._fold if need_params else None
         gjoint, _ = chain_backward(self.pDxz, s_dxz, glogit.reshape(B, 1, 1, 1), s_dxz[0].in_shape[3], True,
-                                   need_params, dst, **self._join_in())
+                                   need_params, dst, fold=fold, **self._join_in())
         gjoint = gjoint.reshape(B, -1)
         gx0 = gz = None
         if need_params or need_x:
             gx0, _ = chain_backward(self.pDx, s_dx, *self._branch_grad(gjoint, 0, B, 0, n_dx), n_log,
-                                    need_x, need_params, dst, gx_planes=planes if need_x else None,
+                                    need_x, need_params, dst, gx_planes=planes if need_x else None, fold=fold,
                                     **self._join_out(gjoint))
         if need_params or need_z:
             nz = gjoint.shape[1] - n_dx
             gz, _ = chain_backward(self.pDz, s_dz, *self._branch_grad(gjoint, 0, B, n_dx, nz), nz, need_z,
-                                   need_params, dst, **self._join_out(gjoint))
+                                   need_params, dst, fold=fold, **self._join_out(gjoint))
+        if fold is not None:
+            fold.flush()          # one launch sums the slabs of all of D's weight gradients
         return gx0, gz
 
     # the join in the backward pass: dxz's first data-gradient epilogue applies the branch ends' act', the branches
@@ -335,14 +341,16 @@ class AliStepper:
                                  nz, True, False, **self._join_out(gjoint))
         # of E's input gradient only the embedding planes are consumed (their tables are parameters of E)
         g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, bool(self._emb_planes), True, dst,
-                                  gx_planes=self._emb_planes or None)
+                                  gx_planes=self._emb_planes or None, fold=self._fold)
         if self._emb_planes:
             self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
         # ... fake pass: only the image path (dxz -> dx) reaches G
         g_x0f, _ = chain_backward(self.pDx, slice_saved(s_dx, 1, 2), *self._branch_grad(gjoint, B, B, 0, n_dx),
                                   n_log, True, False, gx_planes=(0,), **self._join_out(gjoint))
         g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
-        g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst)
+        g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst, fold=self._fold)
+        if self._fold is not None:
+            self._fold.flush()    # one launch sums the slabs of all of E's and G's weight gradients
         g_gin = g_gin.reshape(B, -1)
         off = zin.shape[1]
         for oh, t in zip(onehots, fam.g_tables):

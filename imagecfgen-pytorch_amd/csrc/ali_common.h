@@ -26,7 +26,6 @@ struct Tuning {
   long long wgrad_small;                    // ALI_WGRAD_SMALL
   int wgrad_blocks, wgrad_scap;             // ALI_WGRAD_BLOCKS / ALI_WGRAD_SCAP
   int no_order;                             // ALI_NO_ORDER=1: ignore AliEpilogue.tile_order (A/B measurements)
-  int wgrad_fold;                           // ALI_WGRAD_FOLD: most slabs a weight-gradient launch folds in-kernel (-1: default)
 };
 inline Tuning read_tuning() {
   {
@@ -36,7 +35,6 @@ inline Tuning read_tuning() {
     v.wgrad_small = getenv("ALI_WGRAD_SMALL") ? num("ALI_WGRAD_SMALL") : -1;
     v.wgrad_blocks = (int)num("ALI_WGRAD_BLOCKS"); v.wgrad_scap = (int)num("ALI_WGRAD_SCAP");
     v.no_order = (int)num("ALI_NO_ORDER");
-    v.wgrad_fold = getenv("ALI_WGRAD_FOLD") ? (int)num("ALI_WGRAD_FOLD") : -1;
     return v;
   }
 }

@@ -36,7 +36,6 @@ struct WDesc {
   const _Float16* x16;   // fp16 twins of x / dy (same shapes), or null: the F16 == 2 kernels read these
   const _Float16* dy16;
   int ldd;            // floats between consecutive pixels of dy (Cd, or more when dy is a column range of wider rows)
-  int* ctr;           // split-K arrival counters (one per weight tile, zero between launches): fold in the kernel
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool VECA, bool VECB>
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
           for (int r = 0; r < BROWS8; ++r) sum += red[r * BN + t];
           const int n = n0 + t;
           if (n < d.Cd_log) {
-            if (d.splitk > 1) __hip_atomic_store(&d.dbws[(long long)blockIdx.z * d.Cd + n], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d.splitk > 1) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
             else d.db[n] = sum;
           }
         }
@@ -620,7 +619,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   }
 
   const bool partial = d.splitk > 1;
-  const bool fold = partial && d.ctr != nullptr;   // slabs are summed by the block that arrives last at the tile (below)
   if (do_db && F16 != 2) {   // fold the per-thread column sums over the BROWS row lanes (fixed order), then one store per column
     __syncthreads();
     float* red = &As[0][0];                       // BROWS x BN floats <= tile size
@@ -631,13 +629,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
       for (int r = 0; r < BROWS; ++r) sum += red[r * BN + t];
       const int n = n0 + t;
       if (n < d.Cd_log) {
-        if (partial) __hip_atomic_store(&d.dbws[(long long)blockIdx.z * d.Cd + n], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (partial) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
         else d.db[n] = sum;
       }
     }
   }
   if (partial) {
-    // raw partial tile -> this split's slab (device-scope stores: see the split-K hand-off in gconv.hip)
+    // raw partial tile -> this split's slab; the slabs are summed by wgrad_reduce_tile_kernel / wgrad_fold_multi_kernel.
+    // (Measured and dropped: the last-arriving block of a tile summing the slabs itself, as gconv.hip's split-K does --
+    // store-ack, counter RMW, device-scope loads and the scattered stores are four dependent memory round trips at
+    // the tail of the launch, which cost exactly what the second launch costs.)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 32 + (lane & 31);
@@ -647,81 +648,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < d.Mtot)
-            __hip_atomic_store(&d.ws[(long long)blockIdx.z * d.slab + (long long)m * d.Cd + n], acc[i][j][r],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (m < d.Mtot) d.ws[(long long)blockIdx.z * d.slab + (long long)m * d.Cd + n] = acc[i][j][r];
         }
       }
     }
-    if (!fold) return;            // the stand-alone reduction kernels sum the slabs
-    // Last-arriving block of the tile sums the S slabs in slab order (deterministic whichever block that is) and
-    // writes the parameter layout: same store / counter / load discipline as gconv.hip's split-K (sc1 stores, wait,
-    // barrier, agent-scope RMW, sc1 loads), counter left at zero for the next launch.
-    __shared__ int s_last;
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (t == 0) {
-      int* c = d.ctr + (blockIdx.y * gridDim.x + blockIdx.x);
-      const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = arrived == d.splitk - 1;
-      if (s_last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const unsigned slab_bytes = (unsigned)(d.slab * 4);
-    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)d.ws, 0, (unsigned)(((long long)d.splitk * d.slab + (long long)d.splitk * d.Cd) * 4), 0x00020000);
-    constexpr int kSc1 = 16;      // cache policy: device scope
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        unsigned voff[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          voff[r] = (n < d.Cd && m < d.Mtot) ? (unsigned)(m * d.Cd + n) * 4u : OOB;
-        }
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = 0.f;
-        int sl0 = 0;
-        for (; sl0 + 4 <= d.splitk; sl0 += 4) {      // 4 slabs x 16 rows requested before the first is consumed
-          float tmp[4][16];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const unsigned soff = (unsigned)(sl0 + u) * slab_bytes;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              tmp[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, (int)voff[r], (int)soff, kSc1));
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += tmp[u][r];
-        }
-        for (; sl0 < d.splitk; ++sl0) {
-          const unsigned soff = (unsigned)sl0 * slab_bytes;
-          float tmp[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            tmp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, (int)voff[r], (int)soff, kSc1));
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += tmp[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = v[r];
-      }
-    }
-    if (do_db && t < BN && n0 + t < d.Cd_log) {     // the bias gradient's slabs [S][Cd] sit behind the weight slabs
-      const unsigned base = (unsigned)((long long)d.splitk * d.slab * 4);
-      float sum = 0.f;
-      for (int sl = 0; sl < d.splitk; ++sl)
-        sum += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                   rws, (int)((unsigned)(sl * d.Cd + n0 + t) * 4u), (int)base, kSc1));
-      d.db[n0 + t] = sum;
-    }
+    return;
   }
   // Final tile -> parameter layout dst[dc*s_dc + gc*s_gc + tap*s_tap], transposed through LDS one 32x32 MFMA tile per
   // wave at a time (the operand tiles are dead): a lane then walks the gathered channels of ONE dense channel, whose
@@ -791,21 +722,38 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int Mto
 constexpr int kSlabPad = 96;
 constexpr int kRedRows = 64, kRedGroups = 16, kRedLds = 256;   // rows per tile, slab groups, groups*rows bound
 template <int TD>
-__global__ void __launch_bounds__(256)
-wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log, int Cd_log,
-                         long long s_dc, long long s_gc, long long s_tap, float* __restrict__ dst,
-                         const float* __restrict__ dbws, float* __restrict__ db, int G, int T, int SGN, long long slab) {
-  __shared__ float part[kRedLds * (TD + 1)];   // [SGN][RT][TD+1], SGN*RT <= kRedLds
+__device__ __forceinline__ void reduce_tile_body(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log,
+                                                 int Cd_log, long long s_dc, long long s_gc, long long s_tap,
+                                                 float* __restrict__ dst, const float* __restrict__ dbws,
+                                                 float* __restrict__ db, int G, int T, int SGN, long long slab,
+                                                 int bx, int by, int lin, float* part) {
   const int tid = threadIdx.x;
-  if (db) {
-    const int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
-    if (i < Cd_log) {
-      float v = 0.f;
-      for (int s = 0; s < S; ++s) v += dbws[(long long)s * Cd + i];
-      db[i] = v;
+  if (db && lin * 32 < Cd_log) {
+    // bias gradient: block `lin` folds columns [32*lin, 32*lin + 32) -- 8 thread groups take every 8th slab (four loads
+    // in flight each), combined in group order: a fixed summation order, and no chain of S dependent loads
+    const int c = lin * 32 + (tid & 31), sg = tid >> 5;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < Cd_log) {
+      int sl = sg;
+      for (; sl + 24 < S; sl += 32) {
+        a0 += dbws[(long long)sl * Cd + c];
+        a1 += dbws[(long long)(sl + 8) * Cd + c];
+        a2 += dbws[(long long)(sl + 16) * Cd + c];
+        a3 += dbws[(long long)(sl + 24) * Cd + c];
+      }
+      for (; sl < S; sl += 8) a0 += dbws[(long long)sl * Cd + c];
     }
+    part[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < 32 && c < Cd_log) {
+      float v = part[tid];
+#pragma unroll
+      for (int g8 = 1; g8 < 8; ++g8) v += part[g8 * 32 + tid];
+      db[c] = v;
+    }
+    __syncthreads();
   }
-  const int gc0 = blockIdx.x * G, dc0 = blockIdx.y * TD;
+  const int gc0 = bx * G, dc0 = by * TD;
   const int RT = G * T;
   constexpr int C4 = TD / 4;
   const int slots = RT * C4;
@@ -854,6 +802,45 @@ wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, 
   }
 }
 
+template <int TD>
+__global__ void __launch_bounds__(256)
+wgrad_reduce_tile_kernel(const float* __restrict__ ws, int S, int Mtot, int Cg, int Cd, int Cg_log, int Cd_log,
+                         long long s_dc, long long s_gc, long long s_tap, float* __restrict__ dst,
+                         const float* __restrict__ dbws, float* __restrict__ db, int G, int T, int SGN, long long slab) {
+  __shared__ float part[kRedLds * (TD + 1)];   // [SGN][RT][TD+1], SGN*RT <= kRedLds
+  reduce_tile_body<TD>(ws, S, Mtot, Cg, Cd, Cg_log, Cd_log, s_dc, s_gc, s_tap, dst, dbws, db, G, T, SGN, slab,
+                       blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x, part);
+}
+
+// The same reduction for up to kFoldJobs weight-gradient launches in ONE launch (ali_wgrad_fold_multi): a backward pass
+// leaves the slabs of all its layers in place and folds them together in front of the optimiser step -- a dozen
+// 10-us launches (each mostly launch latency: a few MB of slabs) become one that streams them at HBM rate.
+constexpr int kFoldJobs = 12;
+struct FoldJob {
+  const float* ws; float* dst; const float* dbws; float* db;
+  long long slab, s_dc, s_gc, s_tap;
+  int S, Mtot, Cg, Cd, Cg_log, Cd_log, G, T, SGN, nbx, tile0, TD;
+};
+struct FoldJobs { int n, total; FoldJob j[kFoldJobs]; };
+__global__ void __launch_bounds__(256) wgrad_fold_multi_kernel(const FoldJobs jobs) {
+  __shared__ float part[kRedLds * 33];
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < jobs.n; ++i)
+    if ((int)blockIdx.x >= jobs.j[i].tile0) k = i;
+  const FoldJob& J = jobs.j[k];
+  const int lin = blockIdx.x - J.tile0;
+  const int by = lin / J.nbx, bx = lin - by * J.nbx;
+#define FOLD_TD(TD_)                                                                                                \
+  reduce_tile_body<TD_>(J.ws, J.S, J.Mtot, J.Cg, J.Cd, J.Cg_log, J.Cd_log, J.s_dc, J.s_gc, J.s_tap, J.dst, J.dbws, J.db, \
+                        J.G, J.T, J.SGN, J.slab, bx, by, lin, part)
+  if (J.TD == 32) FOLD_TD(32);          // block-uniform
+  else if (J.TD == 16) FOLD_TD(16);
+  else if (J.TD == 8) FOLD_TD(8);
+  else FOLD_TD(4);
+#undef FOLD_TD
+}
+
 }  // namespace ali
 
 using namespace ali;
@@ -861,11 +848,13 @@ using namespace ali;
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
                                    int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
                                    const int32_t* pixtab, int32_t mfma_f16, const void* x16, const void* dy16,
-                                   int32_t dy_ld, void* ws, size_t ws_bytes, ali_stream_t stream_) {
+                                   int32_t dy_ld, AliWgradFold* fold, void* ws, size_t ws_bytes,
+                                   ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
     return ALI_ERR_BAD_ARG;
   }
+  if (fold) fold->S = 0;
   hipStream_t stream = (hipStream_t)stream_;
   void* const ws_all = ws;
   const size_t ws_all_bytes = ws_bytes;
@@ -930,13 +919,6 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   d.db = fast ? db : nullptr;
   d.slab = (long long)d.Mtot * g->K + kSlabPad;
   d.dbws = d.ws + (size_t)S * d.slab;
-  // few slabs per tile: the block that finishes a tile last sums them itself (no second launch); long folds (first
-  // layers of the spectrogram models: hundreds of slabs for a handful of tiles) keep the wide stand-alone reduction
-  int fold_cap = 64;
-  if (tuning().wgrad_fold >= 0) fold_cap = tuning().wgrad_fold;
-  if (fast && S > 1 && S <= fold_cap && blocks <= (long long)(kWsReserved / sizeof(int)) &&
-      ((size_t)S * d.slab + (size_t)S * g->K) * sizeof(float) < (1ull << 32))
-    d.ctr = reinterpret_cast<int*>(ws_all);
   dim3 grid(tiles_m, tiles_n, S), block(256);
   if (fast) {
     const unsigned xb = (unsigned)(x_elems * 4), yb = (unsigned)(dy_elems * 4);
@@ -978,7 +960,16 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   }
   int rc = check_launch("wgrad_kernel");
   if (rc) return rc;
-  if (S > 1 && !d.ctr) {
+  if (S > 1 && fold && fast && g->R * g->S <= kRedRows) {
+    // deferred: the caller keeps the slabs (ws) untouched and folds them with ali_wgrad_fold_multi
+    fold->ws = d.ws; fold->dst = dst; fold->dbws = d.dbws; fold->db = d.db;
+    fold->slab = d.slab; fold->s_dc = s_dc; fold->s_gc = s_gc; fold->s_tap = s_tap;
+    fold->S = S; fold->Mtot = d.Mtot; fold->Cg = d.Cg; fold->Cd = d.Cd; fold->Cg_log = Cg_log; fold->Cd_log = Cd_log;
+    fold->T = g->R * g->S; fold->reserved = 0;
+    fold->ws_used = (uint64_t)kWsReserved + ((uint64_t)S * d.slab + (uint64_t)S * g->K) * sizeof(float);
+    return ALI_OK;
+  }
+  if (S > 1) {
     const long long total = (long long)d.Mtot * g->K;
     const int T = g->R * g->S;
     if (fast && T <= kRedRows) {
@@ -1012,6 +1003,50 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (!rc && db && !fast)   // generic path: bias gradient by the stand-alone column-sum kernels
     rc = ali_colsum(dy, (int64_t)d.npix, Cd_log, g->K, db, ws_all, ws_all_bytes, stream_);
   return rc;
+}
+
+extern "C" int ali_wgrad_fold_multi(int32_t n, const AliWgradFold* jobs, ali_stream_t stream_) {
+  if (n < 0 || (n > 0 && !jobs)) { set_error("ali_wgrad_fold_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int j0 = 0; j0 < n; j0 += kFoldJobs) {
+    FoldJobs fj;
+    memset(&fj, 0, sizeof(fj));
+    int tiles = 0;
+    for (int i = j0; i < n && i < j0 + kFoldJobs; ++i) {
+      const AliWgradFold& a = jobs[i];
+      if (a.S < 1 || a.T < 1 || a.T > kRedRows || !a.ws || !a.dst || a.Cg < 1 || a.Cd < 1 || (a.Cd % 4) != 0) {
+        set_error("ali_wgrad_fold_multi: bad job %d", i);
+        return ALI_ERR_BAD_ARG;
+      }
+      FoldJob& J = fj.j[fj.n++];
+      J.ws = a.ws; J.dst = a.dst; J.dbws = a.dbws; J.db = a.db;
+      J.slab = a.slab; J.s_dc = a.s_dc; J.s_gc = a.s_gc; J.s_tap = a.s_tap;
+      J.S = a.S; J.Mtot = a.Mtot; J.Cg = a.Cg; J.Cd = a.Cd; J.Cg_log = a.Cg_log; J.Cd_log = a.Cd_log; J.T = a.T;
+      // tile: G gathered channels x T taps (16..64 rows) by 32 dense channels; G grows while the job stays deep
+      // ... and narrower than 32 dense channels when a block would otherwise walk more than ~128 KB of slabs (the
+      // first layers' hundreds of slabs for a handful of tiles): the launch lasts as long as its longest block
+      int G = (16 + a.T - 1) / a.T;
+      int TD = 32;
+      while (TD > 4 && (long long)a.S * G * a.T * TD * 4 > (128 << 10)) TD >>= 1;
+      auto nblk = [&](int G_) { return (long long)((a.Cg + G_ - 1) / G_) * ((a.Cd + TD - 1) / TD); };
+      while (TD == 32 && 2 * G * a.T <= kRedRows && nblk(2 * G) >= 2 * kNumCU) G *= 2;
+      J.TD = TD;
+      int SGN = kRedLds / (G * a.T);
+      if (SGN > kRedGroups) SGN = kRedGroups;
+      if (SGN > a.S) SGN = a.S;
+      J.G = G; J.SGN = SGN;
+      J.nbx = (a.Cg + G - 1) / G;
+      J.tile0 = tiles;
+      const long long nb = nblk(G);
+      if (nb * 32 < a.Cd_log || tiles + nb > (1 << 30)) { set_error("ali_wgrad_fold_multi: job %d too large", i); return ALI_ERR_BAD_ARG; }
+      tiles += (int)nb;
+    }
+    fj.total = tiles;
+    if (tiles > 0) hipLaunchKernelGGL(wgrad_fold_multi_kernel, dim3(tiles), dim3(256), 0, stream, fj);
+    int rc = check_launch("wgrad_fold_multi_kernel");
+    if (rc) return rc;
+  }
+  return ALI_OK;
 }
 
 extern "C" int ali_wgrad_pixtab(const AliConvGeom* g, int32_t* out, ali_stream_t stream) {

@@ -111,6 +111,21 @@ typedef struct {
   int32_t out_ld;
 } AliEpilogue;
 
+/* A weight-gradient launch that splits the pixel range writes S partial results ("slabs") into its workspace and
+ * sums them in a second launch.  With `fold` given, ali_conv_bwd_weight skips that second launch and describes it here
+ * instead (S > 0; S == 0: nothing was deferred, dst is final): the caller gives every such launch of a backward pass its
+ * own workspace region (ws_used bytes from the start of the ws it passed stay live) and folds them all with ONE
+ * ali_wgrad_fold_multi in front of the optimiser step. */
+typedef struct AliWgradFold {
+  const float* ws;
+  float* dst;
+  const float* dbws;
+  float* db;
+  int64_t slab, s_dc, s_gc, s_tap;
+  int32_t S, Mtot, Cg, Cd, Cg_log, Cd_log, T, reserved;
+  uint64_t ws_used;
+} AliWgradFold;
+
 /* ---- implicit-GEMM convolutions (fp32 MFMA v_mfma_f32_32x32x2_f32) -------
  * ali_conv_fwd       : nn.Conv2d forward  (mnist.py:31-39,100-135; c2d(...) in
  *                      audio_mnist.py:186-198 etc.) and ConvTranspose2d dgrad.
@@ -154,7 +169,11 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                                                              launches that produced them): read instead of x / dy */,
                         int32_t dy_ld /* floats between consecutive pixels of dy; 0 = K (dense).  > K: dy is a column
                                          range of wider rows (AliEpilogue.in_ld / out_ld); twins are then not read */,
+                        AliWgradFold* fold /* optional: defer the slab reduction, see AliWgradFold */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
+/* Folds the slabs of up to any number of deferred weight-gradient launches (jobs[i].S > 0 each) in as few launches as
+ * possible (12 jobs per launch), writing every dst / db. */
+int ali_wgrad_fold_multi(int32_t n, const AliWgradFold* jobs, ali_stream_t stream);
 /* Per-geometry table for ali_conv_bwd_weight: entry i (2 x int32) of output pixel i = (b,p,q) holds the byte offset of
  * x[b, p*stride, q*stride, 0] and the packed pair (p*stride, q*stride); the kernel adds its tap's (r-pad, s-pad).  With it the kernel's gather
  * addresses cost a table read instead of two integer divisions per 16 bytes (fp32 MFMA shares the vector issue
