@@ -93,12 +93,14 @@ SIGNATURES = {
     "ali_plane_table_grad": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ali_col2im": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 12 + [c_float, c_void_p]),
-    "ali_tconv1_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_float, c_void_p]),
+    "ali_tconv1_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_float, c_void_p, c_int32,
+                                                                                            c_void_p]),
     "ali_tconv1_dgrad": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p] + [c_int32] * 7
                          + [c_void_p]),
     "ali_tconv1_wgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int64, c_int64]
                          + [c_int32] * 7 + [c_void_p, c_size_t, c_void_p]),
     "ali_last_error": (c_char_p, []),
+    "ali_copy_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "ali_version": (c_int32, []),
     "ali_reload_tuning": (None, []),
 }

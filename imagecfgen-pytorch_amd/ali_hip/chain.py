@@ -135,13 +135,19 @@ class ChainPlan:
                 if dst is not None:
                     return dst.reshape(shape)
                 return (torch.zeros if zero else torch.empty)(*shape, device=dev)
-            if which == "scatter":            # ConvT [Ci][Co][R][S] -> rows n = tap*Co + co, columns ci
+            if which == "scatter":            # ConvT [Ci][Co][R][S] -> rows n = tap*Co + co, columns ci (pad: 0)
                 Ci, Co, R, S = w.shape
                 out = buf(R * S * Co, 1, cin_stride, zero=True)
-                out[:, 0, :Ci].copy_(w.detach().permute(2, 3, 1, 0).reshape(R * S * Co, Ci))
+                # as a pack: "row" tap, "tap" co, channel ci -- joins the batched re-pack launch of an optimiser step
+                ops.pack_weights(w.detach(), out, R * S, Co, Ci, cin_stride, 1, R * S, Co * R * S)
                 return out
             if isinstance(which, tuple) and which[0] == "scatter_dgrad":   # Conv [K][C][R][S] -> rows tap*NP + j, cols k
                 K, C, R, S = w.shape
+                if len(which[1]) == 1:        # one plane: rows = taps, channel k; source = the plane's [K][.][R][S] slice
+                    out = buf(R * S, 1, K)
+                    src = w.detach().reshape(-1)[which[1][0] * R * S:]
+                    ops.pack_weights(src, out, R * S, 1, K, K, 1, 0, C * R * S)
+                    return out
                 sel = torch.stack([w.detach()[:, c] for c in which[1]], dim=0)          # [NP][K][R][S], slices only
                 out = buf(R * S * len(which[1]), 1, K)
                 out[:, 0, :].copy_(sel.permute(2, 3, 0, 1).reshape(R * S * len(which[1]), K))
@@ -537,12 +543,10 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
         if i == 0 and gx_planes is not None and sv.bn is None and _first_conv_direct(st, c_in_log):
             planes = torch.empty(B, H, W, len(gx_planes), dtype=torch.float32, device=gy.device)
             wd = plan.packed(st, "dgrad", Cp)                  # [Cpad][T][K]: row c is the [T][K] filter of plane c
-            for j, c in enumerate(gx_planes):
+            for j, c in enumerate(gx_planes):     # (the input's Dropout2d mask column scales the plane in the same launch)
                 ops.tconv1_fwd(g_pre, wd[c], None, planes[..., j], B, P, Q, K, m.kernel_size[0], m.kernel_size[1],
-                               m.padding[0], len(gx_planes), ACT_NONE, 0.0)
-            if sv.mask is not None:
-                cols = torch.cat([sv.mask[:, c:c + 1] for c in gx_planes], dim=1)   # slices only: graph-capture safe
-                planes = planes * cols.reshape(B, 1, 1, -1)
+                               m.padding[0], len(gx_planes), ACT_NONE, 0.0,
+                               rowscale=None if sv.mask is None else sv.mask[:, c])
             gx = planes
             break
         if i == 0 and sv.bn is None and _scatter_dgrad(st, gx_planes):

@@ -392,12 +392,15 @@ def _ptr(t):
     return c_void_p(t.data_ptr())
 
 
-def tconv1_fwd(big, w_tk, bias, out, B, P, Q, K, R, S, pad, ostride, act, slope):
+def tconv1_fwd(big, w_tk, bias, out, B, P, Q, K, R, S, pad, ostride, act, slope, rowscale=None):
+    """``rowscale``: optional [B] view (any stride) of per-sample factors applied to the output."""
     lib = _lib.load()
 
     def go():
         _lib.check(lib.ali_tconv1_fwd(_chk(big, "big"), _chk(w_tk, "w"), None if bias is None else _ptr(bias),
-                                      _ptr(out), B, P, Q, K, R, S, pad, ostride, act, slope, _stream()),
+                                      _ptr(out), B, P, Q, K, R, S, pad, ostride, act, slope,
+                                      None if rowscale is None else _ptr(rowscale),
+                                      0 if rowscale is None else rowscale.stride(0), _stream()),
                    "ali_tconv1_fwd")
     _launch("tconv1_fwd", 2.0 * B * P * Q * K * R * S, (0,) * 10, go)
     return out
@@ -491,6 +494,24 @@ def pack_weights(src, dst, N, T, C, Cpad, s_n, s_tap, s_c):
         return dst
     _launch_packs([(src, dst, N, T, C, Cpad, s_n, s_tap, s_c)])
     return dst
+
+
+def copy_multi(pairs):
+    """[(dst, src), ...]: dst.copy_(src) for all pairs -- same-dtype contiguous CUDA pairs share one launch
+    (include/ali_hip.h: ali_copy_multi), anything else falls back to Tensor.copy_."""
+    fast = []
+    for dst, src in pairs:
+        if (dst.is_cuda and src.is_cuda and dst.device == src.device and dst.dtype == src.dtype and dst.shape == src.shape
+                and dst.is_contiguous() and src.is_contiguous() and dst.element_size() % 4 == 0 and dst.numel() > 0):
+            fast.append((dst, src))
+        else:
+            dst.copy_(src)
+    if fast:
+        n = len(fast)
+        srcs = (c_void_p * n)(*[s_.data_ptr() for _, s_ in fast])
+        dsts = (c_void_p * n)(*[d_.data_ptr() for d_, _ in fast])
+        sizes = (ctypes.c_int64 * n)(*[d_.numel() * d_.element_size() for d_, _ in fast])
+        _lib.check(_lib.load().ali_copy_multi(n, srcs, dsts, sizes, _stream()), "ali_copy_multi")
 
 
 def act_bwd(gy, y, act, slope, out=None):

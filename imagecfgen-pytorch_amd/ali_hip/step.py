@@ -627,10 +627,7 @@ class AliStepper:
             self._restore(snap)                 # capture executes nothing, but the eager collectives above ran
             self._graph[key] = (graphs, st, cx["out"])
         graphs, st, res = self._graph[key]
-        st["images"].copy_(images)
-        st["z"].copy_(z)
-        for k, v in c.items():
-            st["c"][k].copy_(v)
+        ops.copy_multi([(st["images"], images), (st["z"], z)] + [(st["c"][k], v) for k, v in c.items()])
         pending = None
         for g, group, wait in graphs:
             if wait and pending is not None:
@@ -660,10 +657,7 @@ class AliStepper:
                 res = self._iteration(st["images"], st["c"], st["z"], do_eg)
             self._graph[key] = (graph, st, res)
         graph, st, res = self._graph[key]
-        st["images"].copy_(images)
-        st["z"].copy_(z)
-        for k, v in c.items():
-            st["c"][k].copy_(v)
+        ops.copy_multi([(st["images"], images), (st["z"], z)] + [(st["c"][k], v) for k, v in c.items()])
         graph.replay()
         return res
 

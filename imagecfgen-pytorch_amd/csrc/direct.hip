@@ -35,6 +35,8 @@ struct T1Desc {
   int ostride;         // element stride of the fwd output
   int act; float slope;
   int dact; float dslope;
+  const float* rowscale;   // fwd: optional per-sample factor rowscale[b * rowscale_ld] on the output (a Dropout2d mask column)
+  int rowscale_ld;
 };
 
 // ---------------------------------------------------------------- forward: big (K ch) -> small (1 ch)
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void tconv1_fwd_kernel(const T1Desc d) {
   if (ty < T1_RB && h < d.H && wq < d.W) {
     float v = acc + (d.bias ? d.bias[0] : 0.f);
     v = apply_act(v, d.act, d.slope);
+    if (d.rowscale) v *= d.rowscale[(long long)b * d.rowscale_ld];
     d.out[((long long)(b * d.H + h) * d.W + wq) * d.ostride] = v;
   }
 }
@@ -304,7 +307,7 @@ using namespace ali;
 
 extern "C" int ali_tconv1_fwd(const float* big, const float* w_tk, const float* bias, float* out, int32_t B, int32_t P,
                               int32_t Q, int32_t K, int32_t R, int32_t S, int32_t pad, int32_t ostride, int32_t act,
-                              float slope, ali_stream_t stream) {
+                              float slope, const float* rowscale, int32_t rowscale_ld, ali_stream_t stream) {
   const int H = P + R - 1 - 2 * pad, W = Q + S - 1 - 2 * pad;
   if (!big || !w_tk || !out || ostride < 1) { set_error("ali_tconv1_fwd: bad argument"); return ALI_ERR_BAD_ARG; }
   int rc = t1_check("ali_tconv1_fwd", B, P, Q, K, H, W, R, S, pad);
@@ -313,6 +316,7 @@ extern "C" int ali_tconv1_fwd(const float* big, const float* w_tk, const float* 
   d.big = big; d.w = w_tk; d.bias = bias; d.out = out;
   d.B = B; d.P = P; d.Q = Q; d.K = K; d.H = H; d.W = W; d.R = R; d.S = S; d.pad = pad;
   d.ostride = ostride; d.act = act; d.slope = slope;
+  d.rowscale = rowscale; d.rowscale_ld = rowscale_ld;
   const size_t lds = ((size_t)(T1_RB + R - 1) * (T1_CB + S - 1) * T1_LDP + (size_t)R * S * K) * sizeof(float);
   dim3 grid((W + T1_CB - 1) / T1_CB, (H + T1_RB - 1) / T1_RB, B);
   hipLaunchKernelGGL(tconv1_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, d);

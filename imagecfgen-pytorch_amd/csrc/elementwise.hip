@@ -845,6 +845,25 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
   }
 }
 
+// ---- several small device-to-device copies in one launch (the step's inputs into the captured graph's buffers) --------
+constexpr int kCopyJobs = 8;
+struct CopyJobs { int n; const unsigned* src[kCopyJobs]; unsigned* dst[kCopyJobs]; long long words[kCopyJobs]; int blk0[kCopyJobs + 1]; };
+__global__ void __launch_bounds__(256) copy_multi_kernel(const CopyJobs jobs) {
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < jobs.n; ++i)
+    if ((int)blockIdx.x >= jobs.blk0[i]) k = i;
+  const long long i0 = ((long long)(blockIdx.x - jobs.blk0[k]) * 256 + threadIdx.x) * 4;
+  const long long n = jobs.words[k];
+  const unsigned* s = jobs.src[k];
+  unsigned* d = jobs.dst[k];
+  if (i0 + 4 <= n && ((((unsigned long long)s) | ((unsigned long long)d)) & 15ull) == 0) {
+    *reinterpret_cast<uint4*>(d + i0) = *reinterpret_cast<const uint4*>(s + i0);
+  } else {
+    for (long long i = i0; i < n && i < i0 + 4; ++i) d[i] = s[i];
+  }
+}
+
 }  // namespace ali
 
 using namespace ali;
@@ -901,6 +920,34 @@ extern "C" int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, f
   jobs.n = n_jobs;
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)blk), dim3(kEwBlock), 0, ST(stream), jobs);
   return check_launch("pack_weights_multi_kernel");
+}
+
+extern "C" int ali_copy_multi(int32_t n, const void* const* src, void* const* dst, const int64_t* bytes, ali_stream_t stream) {
+  if (n < 0 || (n > 0 && (!src || !dst || !bytes))) { set_error("ali_copy_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+  for (int j0 = 0; j0 < n; j0 += kCopyJobs) {
+    CopyJobs cj;
+    memset(&cj, 0, sizeof(cj));
+    int blocks = 0;
+    for (int i = j0; i < n && i < j0 + kCopyJobs; ++i) {
+      if (!src[i] || !dst[i] || bytes[i] < 0 || (bytes[i] & 3) || ((unsigned long long)src[i] & 3) || ((unsigned long long)dst[i] & 3)) {
+        set_error("ali_copy_multi: job %d: pointers and sizes must be multiples of 4 bytes", i);
+        return ALI_ERR_BAD_ARG;
+      }
+      const int k = cj.n++;
+      cj.src[k] = reinterpret_cast<const unsigned*>(src[i]);
+      cj.dst[k] = reinterpret_cast<unsigned*>(dst[i]);
+      cj.words[k] = bytes[i] / 4;
+      cj.blk0[k] = blocks;
+      const long long nb = (cj.words[k] + 1023) / 1024;
+      if (blocks + nb > (1 << 30)) { set_error("ali_copy_multi: too large"); return ALI_ERR_BAD_ARG; }
+      blocks += (int)nb;
+    }
+    cj.blk0[cj.n] = blocks;
+    if (blocks > 0) hipLaunchKernelGGL(copy_multi_kernel, dim3(blocks), dim3(256), 0, ST(stream), cj);
+    int rc = check_launch("copy_multi_kernel");
+    if (rc) return rc;
+  }
+  return ALI_OK;
 }
 
 extern "C" int ali_act_bwd(const float* gy, const float* y, float* gpre, int64_t n, int32_t act, float slope,

@@ -192,7 +192,9 @@ int ali_wgrad_pixtab(const AliConvGeom* g, int32_t* out, ali_stream_t stream);
  * `sstride` / `ostride`: element stride of the 1-channel map when it is one plane of an NHWC tensor. */
 int ali_tconv1_fwd(const float* big, const float* w_tk, const float* bias, float* out, int32_t B, int32_t P,
                    int32_t Q, int32_t K, int32_t R, int32_t S, int32_t pad, int32_t ostride, int32_t act,
-                   float slope, ali_stream_t stream);
+                   float slope, const float* rowscale /* optional: out[b,..] *= rowscale[b * rowscale_ld] (the column of
+                   a Dropout2d mask when `out` is one plane of a masked input's gradient) */, int32_t rowscale_ld,
+                   ali_stream_t stream);
 int ali_tconv1_dgrad(const float* small, int32_t sstride, const float* w_tk, const float* dact_y, int32_t dact,
                      float dslope, float* gbig, int32_t B, int32_t P, int32_t Q, int32_t K, int32_t R, int32_t S,
                      int32_t pad, ali_stream_t stream);
@@ -345,6 +347,9 @@ int ali_spect_post(const float* y, int32_t B, int32_t T, int32_t F, const float*
                    float* out, ali_stream_t stream);
 
 const char* ali_last_error(void);
+/* n device-to-device copies (dst[i] <- src[i], bytes[i] each; pointers and sizes multiples of 4) in one launch per 8:
+ * the per-step refresh of the input buffers a captured HIP graph reads. */
+int ali_copy_multi(int32_t n, const void* const* src, void* const* dst, const int64_t* bytes, ali_stream_t stream);
 int ali_version(void);
 /* Re-read the developer tuning variables (ALI_SPLITK, ALI_NO_ORDER, ...: csrc/ali_common.h) from the environment;
  * they are otherwise read once per process.  Tests and sweeps only. */

@@ -465,6 +465,11 @@ def test_direct_one_channel_kernels(B, K, P, R, pad):
     y4 = torch.zeros(B, H, H, 4, device="cuda")
     ops.tconv1_fwd(xin, w_tk, b.cuda(), y4[..., 2], B, P, P, K, R, R, pad, 4, ops.ACT_TANH, 0.0)
     close(y4[..., 2], y[..., 0], rtol=1e-6, what="strided out")
+    # per-sample factor (one column of a [B, C] Dropout2d mask) applied in the same launch
+    m5 = torch.rand(B, 5, generator=g).cuda()
+    ys = torch.empty(B, H, H, 1, device="cuda")
+    ops.tconv1_fwd(xin, w_tk, b.cuda(), ys, B, P, P, K, R, R, pad, 1, ops.ACT_TANH, 0.0, rowscale=m5[:, 3])
+    assert torch.equal(ys, y * m5[:, 3].reshape(B, 1, 1, 1))
     # several small channels at once (first-layer weight gradient dW[k][c][tap]): channel 1 carries gpre
     g4 = torch.randn(B, H, H, 4, generator=g).cuda()
     g4[..., 1] = gpre[..., 0]
