@@ -37,6 +37,10 @@ class AliWgradFold(Structure):
                 ("Cd_log", c_int32), ("T", c_int32), ("reserved", c_int32), ("ws_used", c_uint64)]
 
 
+class AliWgradJob(Structure):
+    _fields_ = [("opaque", c_uint64 * 40)]
+
+
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol include/ali_hip.h declares
@@ -51,7 +55,8 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
-                                      POINTER(AliWgradFold), c_void_p, c_size_t, c_void_p]),
+                                      POINTER(AliWgradFold), POINTER(AliWgradJob), c_void_p, c_size_t, c_void_p]),
+    "ali_wgrad_launch_multi": (c_int32, [c_int32, POINTER(AliWgradJob), c_void_p]),
     "ali_wgrad_fold_multi": (c_int32, [c_int32, POINTER(AliWgradFold), c_void_p]),
     "ali_wgrad_pixtab": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p]),
     "ali_pack_weights": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,

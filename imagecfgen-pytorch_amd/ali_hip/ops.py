@@ -320,6 +320,9 @@ def wgrad_pixtab(g: AliConvGeom, device):
     return tab
 
 
+DEFER_WGRAD_LAUNCH = True     # tests / A-B measurements: False = every weight-gradient GEMM is its own launch
+
+
 class FoldQueue:
     """Deferred slab reductions of the weight-gradient launches of one backward pass (include/ali_hip.h: AliWgradFold):
     ``conv_bwd_weight(..., defer=queue)`` gives each launch its own region of the queue's arena and skips the second
@@ -330,8 +333,11 @@ class FoldQueue:
 
     def __init__(self, device):
         self.device = device
-        self.jobs = []
+        self.jobs = []          # deferred slab reductions
+        self.launches = []      # deferred GEMM launches (AliWgradJob) ...
+        self.keep = []          # ... and the tensors they read / write, alive until flush
         self.off = 0
+        self.flops = 0.0
 
     def arena(self):
         a = FoldQueue._arena.get(self.device.index)
@@ -341,6 +347,14 @@ class FoldQueue:
         return a
 
     def flush(self):
+        if self.launches:
+            arr = (_lib.AliWgradJob * len(self.launches))(*self.launches)
+            n = len(self.launches)
+
+            def go_l():
+                _lib.check(_lib.load().ali_wgrad_launch_multi(n, arr, _stream()), "ali_wgrad_launch_multi")
+            _launch("wgrad_multi", self.flops, (0,) * 10, go_l)
+        self.launches, self.keep, self.flops = [], [], 0.0
         if self.jobs:
             arr = (_lib.AliWgradFold * len(self.jobs))(*self.jobs)
             n = len(self.jobs)
@@ -362,12 +376,14 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
     x16, dy16 = (shadow16(x), shadow16(dy)) if (f16 and not dy_ld) else (None, None)
     if x16 is None or dy16 is None:
         x16 = dy16 = None
-    ws_ptr, ws_n, job = ws.data_ptr(), ws.numel(), None
+    ws_ptr, ws_n, job, lj = ws.data_ptr(), ws.numel(), None, None
     if defer is not None:
         arena = defer.arena()
         left = arena.numel() * 4 - defer.off
         if left >= (32 << 20):                    # a region of its own (else: the shared workspace, immediate fold)
             ws_ptr, ws_n, job = arena.data_ptr() + defer.off, left, _lib.AliWgradFold()
+            if _PROFILE is None and DEFER_WGRAD_LAUNCH:
+                lj = _lib.AliWgradJob()           # (a KernelProfile times every GEMM on its own)
 
     def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _ptr(dy) if dy_ld else _chk(dy, "dy"),
@@ -376,9 +392,16 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
                                            None if tab is None else c_void_p(tab.data_ptr()), f16,
                                            None if x16 is None else c_void_p(x16.data_ptr()),
                                            None if dy16 is None else c_void_p(dy16.data_ptr()), dy_ld,
-                                           None if job is None else byref(job),
+                                           None if job is None else byref(job), None if lj is None else byref(lj),
                                            c_void_p(ws_ptr), ws_n, _stream()), "ali_conv_bwd_weight")
-    _launch("wgrad", *_geom_cost(g), go)
+    if lj is None:
+        _launch("wgrad", *_geom_cost(g), go)
+    else:
+        go()
+        if lj.opaque[0] == 1:
+            defer.launches.append(lj)
+            defer.keep.append((x, dy, dst, db, tab))
+            defer.flops += _geom_cost(g)[0]
     if job is not None and job.S > 0:
         defer.jobs.append(job)
         defer.off += (int(job.ws_used) + 255) // 256 * 256

@@ -13,6 +13,8 @@
 // also scatters to the reference parameter layout.
 #include "ali_common.h"
 #include <string.h>
+#include <algorithm>
+#include <vector>
 
 namespace ali {
 
@@ -224,7 +226,8 @@ typedef short ws4v __attribute__((__vector_size__(4 * sizeof(short))));
 // F16 == 2: both operands come from their fp16 twins in memory (WDesc.x16 / dy16, left by the fp16 launches that produced
 // the tensors): a 16-byte gather carries 8 channels, no conversion work, half the bytes.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB, int F16 = 0>
-__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsigned x_bytes, unsigned dy_bytes) {
+__device__ __forceinline__ void wgrad_fast_body(const WDesc& d, const unsigned x_bytes, const unsigned dy_bytes,
+                                                const int bx_, const int by_, const int bz_) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int pix_begin = blockIdx.z * d.pix_per_split;
+  const int m0 = bx_ * BM, n0 = by_ * BN;
+  const int pix_begin = bz_ * d.pix_per_split;
   const int pix_end = min(d.npix, pix_begin + d.pix_per_split);
   const int PQ = d.P * d.Q;
   const float rPQ = 1.0f / (float)PQ, rQ = 1.0f / (float)d.Q;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
   __syncthreads();
 
   f32x4 ra[AP], rb[BP];
-  const bool do_db = d.db != nullptr && blockIdx.x == 0;
+  const bool do_db = d.db != nullptr && bx_ == 0;
   f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
   // TAB: the pixel's (byte offset, packed position) comes from the per-geometry table, fetched one k-tile ahead of the
   // gather that uses it (entries past pix_end read as 0 = a position outside the map); this thread's tap adds constants
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
           for (int r = 0; r < BROWS8; ++r) sum += red[r * BN + t];
           const int n = n0 + t;
           if (n < d.Cd_log) {
-            if (d.splitk > 1) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
+            if (d.splitk > 1) d.dbws[(long long)bz_ * d.Cd + n] = sum;
             else d.db[n] = sum;
           }
         }
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
       for (int r = 0; r < BROWS; ++r) sum += red[r * BN + t];
       const int n = n0 + t;
       if (n < d.Cd_log) {
-        if (partial) d.dbws[(long long)blockIdx.z * d.Cd + n] = sum;
+        if (partial) d.dbws[(long long)bz_ * d.Cd + n] = sum;
         else d.db[n] = sum;
       }
     }
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < d.Mtot) d.ws[(long long)blockIdx.z * d.slab + (long long)m * d.Cd + n] = acc[i][j][r];
+          if (m < d.Mtot) d.ws[(long long)bz_ * d.slab + (long long)m * d.Cd + n] = acc[i][j][r];
         }
       }
     }
@@ -679,6 +682,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsig
       __syncthreads();
     }
   }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB, int F16 = 0>
+__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WDesc d, unsigned x_bytes, unsigned dy_bytes) {
+  wgrad_fast_body<BM, BN, WAVES_M, WAVES_N, TAB, F16>(d, x_bytes, dy_bytes, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several weight-gradient GEMMs in ONE launch (ali_wgrad_launch_multi): the weight gradients of a backward pass depend
+// on nothing but saved activations and the layers' output gradients, and nothing depends on them before the optimiser
+// step -- so their launches are collected and issued together, longest blocks first: one launch instead of one per
+// layer, and the small layers' grids fill the gaps the large ones leave.
+constexpr int kWJobs = 12;
+struct WJob { WDesc d; unsigned xb, yb; int gx, gy, blk0, pad_; };
+struct WJobs { int n, pad_; WJob j[kWJobs]; };
+static_assert(sizeof(WJobs) <= 4000, "kernel argument segment");
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TAB, int F16 = 0>
+__global__ __launch_bounds__(256, 2) void wgrad_fast_multi_kernel(const WJobs jobs) {
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < jobs.n; ++i)
+    if ((int)blockIdx.x >= jobs.j[i].blk0) k = i;
+  const WJob& J = jobs.j[k];
+  const int lin = blockIdx.x - J.blk0;
+  const int bx = lin % J.gx, t2 = lin / J.gx;
+  wgrad_fast_body<BM, BN, WAVES_M, WAVES_N, TAB, F16>(J.d, J.xb, J.yb, bx, t2 % J.gy, t2 / J.gy);
 }
 
 __global__ void wgrad_pixtab_kernel(int npix, int P, int Q, int H, int W, int Cg, int stride, int* __restrict__ out) {
@@ -848,13 +876,14 @@ using namespace ali;
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
                                    int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
                                    const int32_t* pixtab, int32_t mfma_f16, const void* x16, const void* dy16,
-                                   int32_t dy_ld, AliWgradFold* fold, void* ws, size_t ws_bytes,
+                                   int32_t dy_ld, AliWgradFold* fold, AliWgradJob* job, void* ws, size_t ws_bytes,
                                    ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
     return ALI_ERR_BAD_ARG;
   }
   if (fold) fold->S = 0;
+  if (job) job->opaque[0] = 0;
   hipStream_t stream = (hipStream_t)stream_;
   void* const ws_all = ws;
   const size_t ws_all_bytes = ws_bytes;
@@ -939,7 +968,16 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     if (mem16) hipLaunchKernelGGL((wgrad_fast_kernel<BM_, BN_, WMM, WNN, true, 2>), grid, block, 0, stream, d, xb, yb);   \
     else FLAUNCH1(BM_, BN_, WMM, WNN);                                                                            \
   } while (0)
-    if (bm == 64) FLAUNCH(64, 64, 2, 2);
+    static_assert(sizeof(WJob) + 8 <= sizeof(AliWgradJob), "AliWgradJob too small");
+    if (job && fold && bm == 64 && d.pixtab && !f16 && (S == 1 || g->R * g->S <= kRedRows)) {
+      // deferred: the caller launches it with the other weight gradients of the pass (ali_wgrad_launch_multi)
+      WJob wj;
+      memset(&wj, 0, sizeof(wj));
+      wj.d = d; wj.xb = xb; wj.yb = yb; wj.gx = tiles_m; wj.gy = tiles_n; wj.blk0 = S;   // (blk0 carries S until launch)
+      job->opaque[0] = 1;
+      memcpy(&job->opaque[1], &wj, sizeof(wj));
+    }
+    else if (bm == 64) FLAUNCH(64, 64, 2, 2);
     else if (bn == 128) FLAUNCH(128, 128, 2, 2);
     else if (bn == 64) FLAUNCH(128, 64, 2, 2);
     else FLAUNCH1(128, 32, 4, 1);
@@ -1003,6 +1041,37 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (!rc && db && !fast)   // generic path: bias gradient by the stand-alone column-sum kernels
     rc = ali_colsum(dy, (int64_t)d.npix, Cd_log, g->K, db, ws_all, ws_all_bytes, stream_);
   return rc;
+}
+
+extern "C" int ali_wgrad_launch_multi(int32_t n, const AliWgradJob* jobs, ali_stream_t stream_) {
+  if (n < 0 || (n > 0 && !jobs)) { set_error("ali_wgrad_launch_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<WJob> all;
+  for (int i = 0; i < n; ++i) {
+    if (jobs[i].opaque[0] != 1) { set_error("ali_wgrad_launch_multi: job %d was not deferred", i); return ALI_ERR_BAD_ARG; }
+    WJob wj;
+    memcpy(&wj, &jobs[i].opaque[1], sizeof(wj));
+    all.push_back(wj);
+  }
+  // longest blocks first (the dispatcher hands blocks out in order: the short ones fill the tail)
+  std::stable_sort(all.begin(), all.end(), [](const WJob& a, const WJob& b) { return a.d.pix_per_split > b.d.pix_per_split; });
+  for (size_t j0 = 0; j0 < all.size(); j0 += kWJobs) {
+    WJobs wj;
+    memset(&wj, 0, sizeof(wj));
+    long long blocks = 0;
+    for (size_t i = j0; i < all.size() && i < j0 + kWJobs; ++i) {
+      WJob& J = wj.j[wj.n++];
+      J = all[i];
+      const int S = J.blk0;
+      J.blk0 = (int)blocks;
+      blocks += (long long)J.gx * J.gy * S;
+      if (blocks > (1LL << 30)) { set_error("ali_wgrad_launch_multi: grid too large"); return ALI_ERR_BAD_ARG; }
+    }
+    hipLaunchKernelGGL((wgrad_fast_multi_kernel<64, 64, 2, 2, true>), dim3((unsigned)blocks), dim3(256), 0, stream, wj);
+    int rc = check_launch("wgrad_fast_multi_kernel");
+    if (rc) return rc;
+  }
+  return ALI_OK;
 }
 
 extern "C" int ali_wgrad_fold_multi(int32_t n, const AliWgradFold* jobs, ali_stream_t stream_) {

@@ -126,6 +126,14 @@ typedef struct AliWgradFold {
   uint64_t ws_used;
 } AliWgradFold;
 
+/* With `job` given (together with `fold`), ali_conv_bwd_weight does not launch its GEMM either when the launch is of
+ * the common kind (fp32, 64x64 tiles, pixel table): it records it here (opaque[0] = 1; 0 = it was launched as usual) and
+ * the caller issues all recorded launches of a backward pass with ONE ali_wgrad_launch_multi -- in front of
+ * ali_wgrad_fold_multi, after the last of their operands has been produced. */
+typedef struct AliWgradJob {
+  uint64_t opaque[40];
+} AliWgradJob;
+
 /* ---- implicit-GEMM convolutions (fp32 MFMA v_mfma_f32_32x32x2_f32) -------
  * ali_conv_fwd       : nn.Conv2d forward  (mnist.py:31-39,100-135; c2d(...) in
  *                      audio_mnist.py:186-198 etc.) and ConvTranspose2d dgrad.
@@ -170,7 +178,11 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                         int32_t dy_ld /* floats between consecutive pixels of dy; 0 = K (dense).  > K: dy is a column
                                          range of wider rows (AliEpilogue.in_ld / out_ld); twins are then not read */,
                         AliWgradFold* fold /* optional: defer the slab reduction, see AliWgradFold */,
+                        AliWgradJob* job /* optional (needs fold): defer the launch itself, see AliWgradJob */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
+/* Launches deferred weight-gradient GEMMs (jobs[i].opaque[0] == 1 each) together, 12 per launch, longest blocks first.
+ * Every operand and workspace region named at ali_conv_bwd_weight time must still be alive and unchanged. */
+int ali_wgrad_launch_multi(int32_t n, const AliWgradJob* jobs, ali_stream_t stream);
 /* Folds the slabs of up to any number of deferred weight-gradient launches (jobs[i].S > 0 each) in as few launches as
  * possible (12 jobs per launch), writing every dst / db. */
 int ali_wgrad_fold_multi(int32_t n, const AliWgradFold* jobs, ali_stream_t stream);
