@@ -927,7 +927,9 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   const long long blocks = (long long)tiles_m * tiles_n;
   int S = 1;
   const int nkt = (d.npix + wbk - 1) / wbk;
-  int target = 4 * kNumCU;
+  // split over pixels until the launch has `target` blocks: 4 per CU on its own, 1 per CU as one job of a combined launch
+  // (the other layers' blocks fill the machine: measured best of 128 / 256 / 512 / 1024 / 2048 on the MNIST pass)
+  int target = (job && fold) ? kNumCU : 4 * kNumCU;
   if (tuning().wgrad_blocks > 0) target = tuning().wgrad_blocks;
   if (blocks < target && nkt >= 4) {
     S = (int)((target + blocks - 1) / blocks);
