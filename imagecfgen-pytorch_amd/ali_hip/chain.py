@@ -493,6 +493,10 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
         prev = plan.stages[i - 1] if i > 0 else None
         c_in_log = prev.mod.out_channels if (prev is not None and prev.kind != "linear") else (
             (prev.unflat[0] if prev.unflat else prev.mod.out_features) if prev is not None else c_log_in)
+        # a first conv's weight gradient (<= 8 input planes): direct per-channel kernel on its own, but as one more job of
+        # the pass's combined weight-gradient launch when there is one (its 200 x 32 GEMM fills gaps there, and the bias
+        # gradient comes along: measured 7.15 -> 7.08 ms per MNIST iteration)
+        gemm_first = fold is not None and Cp % 4 == 0 and K % 4 == 0
         if need_params:
             # ---- parameter gradients of this stage
             fused_db = None
@@ -503,7 +507,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                     if id(m.bias) in grad_dst:
                         db = grad_dst[id(m.bias)].copy_(db)
                     grads[id(m.bias)] = db
-                elif st.kind == "conv" and not (i == 0 and _first_conv_direct(st, c_in_log)):
+                elif st.kind == "conv" and not (i == 0 and _first_conv_direct(st, c_in_log) and not gemm_first):
                     # Conv2d: the bias gradient is the column sum of the dense wgrad operand -> fused into that launch
                     fused_db = grad_dst.get(id(m.bias))
                     if fused_db is None:
@@ -512,7 +516,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                 else:
                     grads[id(m.bias)] = ops.colsum(rows_out, K, K, g_pre, out=grad_dst.get(id(m.bias)))
             dw = grad_dst[id(m.weight)] if id(m.weight) in grad_dst else torch.empty_like(m.weight)
-            if st.kind == "conv" and i == 0 and _first_conv_direct(st, c_in_log):
+            if st.kind == "conv" and i == 0 and _first_conv_direct(st, c_in_log) and not gemm_first:
                 T = m.kernel_size[0] * m.kernel_size[1]
                 # dW[k][c][tap] = sum big=g_pre[..,k] * small=t[..,c], all input channels in one launch
                 ops.tconv1_wgrad(g_pre, sv.t, Cp, c_in_log, dw, c_in_log * T, 1, T, B, P, Q, K,
