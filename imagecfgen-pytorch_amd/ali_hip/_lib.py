@@ -55,7 +55,7 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
-                                      POINTER(AliWgradFold), POINTER(AliWgradJob), c_void_p, c_size_t, c_void_p]),
+                                      POINTER(AliWgradFold), POINTER(AliWgradJob), c_int32, c_void_p, c_size_t, c_void_p]),
     "ali_wgrad_launch_multi": (c_int32, [c_int32, POINTER(AliWgradJob), c_void_p]),
     "ali_wgrad_fold_multi": (c_int32, [c_int32, POINTER(AliWgradFold), c_void_p]),
     "ali_wgrad_pixtab": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p]),

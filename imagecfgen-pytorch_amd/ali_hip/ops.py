@@ -338,6 +338,7 @@ class FoldQueue:
         self.keep = []          # ... and the tensors they read / write, alive until flush
         self.off = 0
         self.flops = 0.0
+        self.last_n = 1         # deferred launches of the previous flush: how many jobs the coming pass will combine
 
     def arena(self):
         a = FoldQueue._arena.get(self.device.index)
@@ -345,6 +346,10 @@ class FoldQueue:
             a = FoldQueue._arena[self.device.index] = torch.zeros(FoldQueue.arena_bytes // 4, dtype=torch.float32,
                                                                    device=self.device)
         return a
+
+    def split_target(self):
+        """blocks a deferred GEMM should split into: about 2048 in the whole combined launch"""
+        return max(256, min(1024, 2048 // max(self.last_n, 1)))
 
     def flush(self):
         if self.launches:
@@ -354,6 +359,7 @@ class FoldQueue:
             def go_l():
                 _lib.check(_lib.load().ali_wgrad_launch_multi(n, arr, _stream()), "ali_wgrad_launch_multi")
             _launch("wgrad_multi", self.flops, (0,) * 10, go_l)
+            self.last_n = n
         self.launches, self.keep, self.flops = [], [], 0.0
         if self.jobs:
             arr = (_lib.AliWgradFold * len(self.jobs))(*self.jobs)
@@ -393,6 +399,7 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
                                            None if x16 is None else c_void_p(x16.data_ptr()),
                                            None if dy16 is None else c_void_p(dy16.data_ptr()), dy_ld,
                                            None if job is None else byref(job), None if lj is None else byref(lj),
+                                           0 if lj is None else defer.split_target(),
                                            c_void_p(ws_ptr), ws_n, _stream()), "ali_conv_bwd_weight")
     if lj is None:
         _launch("wgrad", *_geom_cost(g), go)

@@ -876,8 +876,8 @@ using namespace ali;
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
                                    int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
                                    const int32_t* pixtab, int32_t mfma_f16, const void* x16, const void* dy16,
-                                   int32_t dy_ld, AliWgradFold* fold, AliWgradJob* job, void* ws, size_t ws_bytes,
-                                   ali_stream_t stream_) {
+                                   int32_t dy_ld, AliWgradFold* fold, AliWgradJob* job, int32_t split_target,
+                                   void* ws, size_t ws_bytes, ali_stream_t stream_) {
   if (!g || !x || !dy || !dst || g->R * g->S > kMaxTaps || g->B <= 0) {
     set_error("ali_conv_bwd_weight: bad argument");
     return ALI_ERR_BAD_ARG;
@@ -927,9 +927,11 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   const long long blocks = (long long)tiles_m * tiles_n;
   int S = 1;
   const int nkt = (d.npix + wbk - 1) / wbk;
-  // split over pixels until the launch has `target` blocks: 4 per CU on its own, 1 per CU as one job of a combined launch
-  // (the other layers' blocks fill the machine: measured best of 128 / 256 / 512 / 1024 / 2048 on the MNIST pass)
-  int target = (job && fold) ? kNumCU : 4 * kNumCU;
+  // split over pixels until the launch has `target` blocks: 4 per CU on its own; a job of a combined launch needs fewer
+  // (the other layers' blocks fill the machine) -- the caller says how many (split_target, from the number of jobs its
+  // passes have: measured best on the MNIST pass of 8 jobs: 256 of 128 / 256 / 512 / 1024 / 2048)
+  int target = 4 * kNumCU;
+  if (job && fold && split_target > 0) target = split_target < kNumCU ? kNumCU : (split_target > 4 * kNumCU ? 4 * kNumCU : split_target);
   if (tuning().wgrad_blocks > 0) target = tuning().wgrad_blocks;
   if (blocks < target && nkt >= 4) {
     S = (int)((target + blocks - 1) / blocks);

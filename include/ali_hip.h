@@ -179,6 +179,8 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                                          range of wider rows (AliEpilogue.in_ld / out_ld); twins are then not read */,
                         AliWgradFold* fold /* optional: defer the slab reduction, see AliWgradFold */,
                         AliWgradJob* job /* optional (needs fold): defer the launch itself, see AliWgradJob */,
+                        int32_t split_target /* with job: blocks this GEMM should have inside the combined launch
+                                                (clamped to 256..1024; 0 = 1024, the stand-alone rule) */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
 /* Launches deferred weight-gradient GEMMs (jobs[i].opaque[0] == 1 each) together, 12 per launch, longest blocks first.
  * Every operand and workspace region named at ali_conv_bwd_weight time must still be alive and unchanged. */
