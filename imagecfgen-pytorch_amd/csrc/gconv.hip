@@ -153,8 +153,19 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
       // "Longest tile first" launches: dispatch slot u -> (rank in the cost-sorted M-tile list, n-tile), n fastest.
       // The dispatcher deals workgroups round-robin over the CUs (measured: CU c of an all-resident grid holds slots
       // c, c+256, c+512, ...), so every CU receives one tile of each cost quartile instead of e.g. four corner tiles.
-      const int rank = u / d.ntile_n;
-      by = u - rank * d.ntile_n;
+      // Slots u, u+8, u+16, ... run on the same XCD (the dispatcher deals slots round-robin over the 8 XCDs): the n-tiles
+      // of an M-tile are placed 8 slots apart, so its gathered rows are fetched into ONE L2 instead of ntile_n of them.
+      const int full = (d.ntile_m >> 3) << 3;
+      int rank;
+      if (u < full * d.ntile_n) {
+        const int grp = u / (8 * d.ntile_n), rem = u - grp * 8 * d.ntile_n;
+        rank = grp * 8 + (rem & 7);
+        by = rem >> 3;
+      } else {
+        const int r = u - full * d.ntile_n;
+        rank = full + r / d.ntile_n;
+        by = r - (r / d.ntile_n) * d.ntile_n;
+      }
       bx = d.order[rank];
     } else {
       by = u / d.ntile_m;
