@@ -27,7 +27,8 @@ class AliEpilogue(Structure):
                 ("bn_mask_ld", c_int32), ("bn_x", c_void_p), ("bn_mean", c_void_p), ("bn_invstd", c_void_p),
                 ("bn_mask_in", c_void_p), ("bn_mask_pre", c_void_p), ("mfma_f16", c_int32),
                 ("in16", c_void_p), ("w16", c_void_p), ("out16", c_void_p),
-                ("tile_order", c_void_p), ("tile_order_n", c_int32), ("in_ld", c_int32), ("out_ld", c_int32)]
+                ("tile_order", c_void_p), ("tile_order_n", c_int32), ("in_ld", c_int32), ("out_ld", c_int32),
+                ("in_ch_live", c_int32)]
 
 
 class AliWgradFold(Structure):
@@ -56,6 +57,7 @@ SIGNATURES = {
     "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                       POINTER(AliWgradFold), POINTER(AliWgradJob), c_int32, c_void_p, c_size_t, c_void_p]),
+    "ali_wgrad_deferrable": (c_int32, [POINTER(AliConvGeom), c_int32]),
     "ali_wgrad_launch_multi": (c_int32, [c_int32, POINTER(AliWgradJob), c_void_p]),
     "ali_wgrad_fold_multi": (c_int32, [c_int32, POINTER(AliWgradFold), c_void_p]),
     "ali_wgrad_pixtab": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p]),

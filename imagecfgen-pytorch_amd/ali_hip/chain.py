@@ -431,6 +431,8 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
         ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope, mask=folded, bn_fwd=bn_fwd)
         if jmask is not None:
             ep.mask, ep.mask_ld = jmask.data_ptr(), jmask.stride(0)
+        if si == 0 and st.kind == "conv" and c_log < Cp:
+            ep.in_ch_live = c_log          # channel padding of a first layer: kernels that can skip it do
         if _scatter_fwd(st, Cp) and folded is None:    # (measured 12 us faster than tconv1_fwd on the MNIST tail, too)
             m = st.mod
             R, S = m.kernel_size
@@ -454,6 +456,11 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
         cur = y
         c_log = out_shape[3]
     return cur, saved
+
+
+def wgrad_geoms(plan: ChainPlan, saved):
+    """geometries of the weight-gradient GEMMs chain_backward(plan, saved, ..., need_params=True) launches"""
+    return [sv.geom for st, sv in zip(plan.stages, saved) if not _is_tconv1(st, sv.in_shape[3])]
 
 
 def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True,

@@ -320,6 +320,18 @@ def wgrad_pixtab(g: AliConvGeom, device):
     return tab
 
 
+_DEFERRABLE = {}
+
+
+def wgrad_deferrable(g: AliConvGeom) -> int:
+    f16 = int(_PRECISION["f16"])
+    key = (f16,) + tuple(getattr(g, n) for n, _ in AliConvGeom._fields_)
+    hit = _DEFERRABLE.get(key)
+    if hit is None:
+        hit = _DEFERRABLE[key] = int(_lib.load().ali_wgrad_deferrable(byref(g), f16))
+    return hit
+
+
 DEFER_WGRAD_LAUNCH = True     # tests / A-B measurements: False = every weight-gradient GEMM is its own launch
 
 
@@ -338,7 +350,7 @@ class FoldQueue:
         self.keep = []          # ... and the tensors they read / write, alive until flush
         self.off = 0
         self.flops = 0.0
-        self.last_n = 1         # deferred launches of the previous flush: how many jobs the coming pass will combine
+        self.n_jobs = 1         # deferrable launches of the pass in progress (expect()): what a combined launch will hold
 
     def arena(self):
         a = FoldQueue._arena.get(self.device.index)
@@ -347,9 +359,14 @@ class FoldQueue:
                                                                    device=self.device)
         return a
 
+    def expect(self, geoms):
+        """Called before a pass's first weight gradient with the geometries of all of them: the number of launches the
+        pass will combine decides how far each is split (a function of the pass alone -- not of what ran before)."""
+        self.n_jobs = max(1, sum(wgrad_deferrable(g) for g in geoms))
+
     def split_target(self):
         """blocks a deferred GEMM should split into: about 2048 in the whole combined launch"""
-        return max(256, min(1024, 2048 // max(self.last_n, 1)))
+        return max(256, min(1024, 2048 // self.n_jobs))
 
     def flush(self):
         if self.launches:
@@ -359,7 +376,6 @@ class FoldQueue:
             def go_l():
                 _lib.check(_lib.load().ali_wgrad_launch_multi(n, arr, _stream()), "ali_wgrad_launch_multi")
             _launch("wgrad_multi", self.flops, (0,) * 10, go_l)
-            self.last_n = n
         self.launches, self.keep, self.flops = [], [], 0.0
         if self.jobs:
             arr = (_lib.AliWgradFold * len(self.jobs))(*self.jobs)

@@ -277,6 +277,9 @@ class AliStepper:
         B = glogit.shape[0]
         dst = self.opt_d.grad_views if need_params else None
         fold = self._fold if need_params else None
+        if fold is not None:
+            fold.expect(_chain.wgrad_geoms(self.pDxz, s_dxz) + _chain.wgrad_geoms(self.pDx, s_dx)
+                        + _chain.wgrad_geoms(self.pDz, s_dz))
         gjoint, _ = chain_backward(self.pDxz, s_dxz, glogit.reshape(B, 1, 1, 1), s_dxz[0].in_shape[3], True,
                                    need_params, dst, fold=fold, **self._join_in())
         gjoint = gjoint.reshape(B, -1)
@@ -340,6 +343,8 @@ class AliStepper:
         g_ex, _ = chain_backward(self.pDz, slice_saved(s_dz, 0, 2), *self._branch_grad(gjoint, 0, B, n_dx, nz),
                                  nz, True, False, **self._join_out(gjoint))
         # of E's input gradient only the embedding planes are consumed (their tables are parameters of E)
+        if self._fold is not None:
+            self._fold.expect(_chain.wgrad_geoms(self.pE, sE) + _chain.wgrad_geoms(self.pG, sG))
         g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, bool(self._emb_planes), True, dst,
                                   gx_planes=self._emb_planes or None, fold=self._fold)
         if self._emb_planes:

@@ -1170,7 +1170,10 @@ struct CFDesc {
   int B, H, W, P, Q, R, S;
 };
 
-template <int TAPS>
+// CL = number of leading input channels that carry data (AliEpilogue.in_ch_live; 8 = all).  CL < 8: the reduction runs
+// over the TAPS*CL live (tap, channel) pairs only, two per MFMA -- MNIST's 5 planes (mnist.py:108: image, digit plane,
+// three attributes) padded to 8 would spend 3/8 of the MFMAs on zeros.
+template <int TAPS, int CL = 8>
 __global__ __launch_bounds__(256) void conv_first_kernel(const CFDesc d) {
   extern __shared__ __attribute__((aligned(16))) float cf_smem[];
   float* img = cf_smem;                                   // [H*W][CF_PIXLD]
@@ -1191,9 +1194,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const CFDesc d) {
   }
   __syncthreads();
   const int lrow = lane & 31, lh = lane >> 5;
-  f32x4 wf[TAPS];                                         // B fragments of every tap: row n = lane&31, channels 4*lh..+3
+  constexpr int KL = TAPS * CL, NS = (KL + 1) / 2;         // live reduction length, MFMA steps (k = 2*step + lh)
+  f32x4 wf[CL == 8 ? TAPS : 1];                            // CL == 8: B fragments of every tap (row n = lane&31, channels 4*lh..+3)
+  float wb[CL == 8 ? 1 : NS];                              // CL < 8: B value and A offset of this lane's k of every step
+  int aoff[CL == 8 ? 1 : NS];
+  if constexpr (CL == 8) {
 #pragma unroll
-  for (int tp = 0; tp < TAPS; ++tp) wf[tp] = *reinterpret_cast<const f32x4*>(wl + lrow * CF_WLD + tp * CF_C + lh * 4);
+    for (int tp = 0; tp < TAPS; ++tp) wf[tp] = *reinterpret_cast<const f32x4*>(wl + lrow * CF_WLD + tp * CF_C + lh * 4);
+  } else {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const int k = 2 * st + lh;
+      const bool live = k < KL;
+      const int kk = live ? k : KL - 1;
+      const int tp = kk / CL, c = kk - tp * CL;
+      const int r = tp / d.S, sx = tp - r * d.S;
+      wb[st] = live ? wl[lrow * CF_WLD + tp * CF_C + c] : 0.f;
+      aoff[st] = (r * d.W + sx) * CF_PIXLD + c;
+    }
+  }
   const AliEpilogue& ep = d.ep;
   const float bias = ep.bias ? ep.bias[lrow] : 0.f;
   const float smask = (ep.bn_part && ep.bn_stat_mask) ? ep.bn_stat_mask[(long long)b * ep.bn_mask_ld + lrow] : 1.f;
@@ -1204,16 +1223,26 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const CFDesc d) {
     const int m = mt * 32 + lrow;
     const int mc = m < PQ ? m : PQ - 1;                   // clamp: rows past the end compute garbage, never stored
     const int p = mc / d.Q, q = mc - p * d.Q;
-    const float* a0 = img + (p * d.W + q) * CF_PIXLD + lh * 4;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (CL == 8) {
+      const float* a0 = img + (p * d.W + q) * CF_PIXLD + lh * 4;
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
-      const int r = tp / d.S, sx = tp - r * d.S;
-      const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + (r * d.W + sx) * CF_PIXLD);
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int r = tp / d.S, sx = tp - r * d.S;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + (r * d.W + sx) * CF_PIXLD);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wf[tp][e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wf[tp][e], acc, 0, 0, 0);
+      }
+    } else {
+      const float* a0 = img + (p * d.W + q) * CF_PIXLD;
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        float av = a0[aoff[st]];
+        if ((KL & 1) && st == NS - 1 && lh) av = 0.f;     // the odd reduction's last step has one live k
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[st], acc, 0, 0, 0);
+      }
     }
     // acc(row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31)
 #pragma unroll
@@ -1260,7 +1289,9 @@ static int conv_first_launch(const AliConvGeom* g, const float* x, const float* 
   if (ep) d.ep = *ep;
   d.B = g->B; d.H = g->H; d.W = g->W; d.P = g->P; d.Q = g->Q; d.R = g->R; d.S = g->S;
   const size_t lds = ((size_t)g->H * g->W * CF_PIXLD + (size_t)CF_K * CF_WLD + 256) * sizeof(float);
-  if (g->R == 5) hipLaunchKernelGGL((conv_first_kernel<25>), dim3(g->B), dim3(256), lds, stream, d);
+  const int live = ep ? ep->in_ch_live : 0;
+  if (g->R == 5 && live == 5) hipLaunchKernelGGL((conv_first_kernel<25, 5>), dim3(g->B), dim3(256), lds, stream, d);
+  else if (g->R == 5) hipLaunchKernelGGL((conv_first_kernel<25>), dim3(g->B), dim3(256), lds, stream, d);
   else hipLaunchKernelGGL((conv_first_kernel<9>), dim3(g->B), dim3(256), lds, stream, d);
   return check_launch("conv_first_kernel");
 }

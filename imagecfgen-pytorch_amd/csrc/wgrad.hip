@@ -873,6 +873,41 @@ __global__ void __launch_bounds__(256) wgrad_fold_multi_kernel(const FoldJobs jo
 
 using namespace ali;
 
+// tile of a weight-gradient launch: [gathered channel x tap] rows by dense channels
+static void wgrad_tile(const AliConvGeom* g, bool fast, bool f16, int& bm, int& bn) {
+  bn = g->K > 64 ? 128 : (g->K > 32 ? 64 : 32);
+  bm = 128;
+  if (!fast) return;
+  const int Mtot = g->R * g->S * g->C;
+  const long long npix = (long long)g->B * g->P * g->Q;
+  // more, smaller tiles while the grid is shallow (see gconv.hip: waits are only hidden by co-resident waves)
+  const long long b64 = (long long)((Mtot + 63) / 64) * ((g->K + 63) / 64);
+  // ... but a long pixel reduction (spectrogram layers) re-reads both operands once per tile pair: larger tiles,
+  // the grid depth comes from the split over pixels
+  long long small_lim = npix >= 200000 ? 16 : 2 * kNumCU;
+  if (tuning().wgrad_small >= 0) small_lim = tuning().wgrad_small;
+  const bool f16_tiles = f16 && g->K > 64 && Mtot >= 128;   // fp16 loop: bytes-bound, big tiles
+  if (g->K > 32 && b64 <= small_lim && !f16_tiles) { bm = 64; bn = 64; }
+  else if (g->K > 64) { bm = 128; bn = 128; }
+  else if (g->K > 32) { bm = 128; bn = 64; }
+  else { bm = 128; bn = 32; }
+}
+
+static bool wgrad_fast_ok(const AliConvGeom* g, int ldd) {
+  const long long x_elems = (long long)g->B * g->H * g->W * g->C;
+  const long long dy_elems = ((long long)g->B * g->P * g->Q - 1) * ldd + g->K;
+  return (g->C % 4) == 0 && (g->K % 4) == 0 && x_elems < (1LL << 30) && dy_elems < (1LL << 30) &&
+         (long long)g->B * g->P * g->Q < (1 << 24);
+}
+
+extern "C" int32_t ali_wgrad_deferrable(const AliConvGeom* g, int32_t mfma_f16) {
+  if (!g || g->B <= 0 || g->R * g->S > kMaxTaps || mfma_f16) return 0;
+  if (!wgrad_fast_ok(g, g->K) || g->H >= 0x2000 || g->W >= 0x2000 || g->pad >= 0x2000) return 0;
+  int bm, bn;
+  wgrad_tile(g, true, false, bm, bn);
+  return bm == 64 ? 1 : 0;
+}
+
 extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, float* dst, int32_t Cg_log,
                                    int32_t Cd_log, int64_t s_dc, int64_t s_gc, int64_t s_tap, float* db,
                                    const int32_t* pixtab, int32_t mfma_f16, const void* x16, const void* dy16,
@@ -905,23 +940,10 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
     set_error("ali_conv_bwd_weight: dy_ld needs the vector kernels (channel counts % 4 == 0) and dy_ld >= K, % 4 == 0");
     return ALI_ERR_BAD_ARG;
   }
-  const bool fast = veca && vecb && x_elems < (1LL << 30) && dy_elems < (1LL << 30) && d.npix < (1 << 24);
+  const bool fast = wgrad_fast_ok(g, d.ldd);
   if (!fast && d.ldd != g->K) { set_error("ali_conv_bwd_weight: dy_ld on a tensor too large for the vector kernels"); return ALI_ERR_BAD_ARG; }
-  int bn = g->K > 64 ? 128 : (g->K > 32 ? 64 : 32);
-  int bm = 128;
-  if (fast) {
-    // more, smaller tiles while the grid is shallow (see gconv.hip: waits are only hidden by co-resident waves)
-    const long long b64 = (long long)((d.Mtot + 63) / 64) * ((g->K + 63) / 64);
-    // ... but a long pixel reduction (spectrogram layers) re-reads both operands once per tile pair: larger tiles,
-    // the grid depth comes from the split over pixels
-    long long small_lim = d.npix >= 200000 ? 16 : 2 * kNumCU;
-    if (tuning().wgrad_small >= 0) small_lim = tuning().wgrad_small;
-    const bool f16_tiles = mfma_f16 && pixtab && g->K > 64 && d.Mtot >= 128;   // fp16 loop: bytes-bound, big tiles
-    if (g->K > 32 && b64 <= small_lim && !f16_tiles) { bm = 64; bn = 64; }
-    else if (g->K > 64) { bm = 128; bn = 128; }
-    else if (g->K > 32) { bm = 128; bn = 64; }
-    else { bm = 128; bn = 32; }
-  }
+  int bm, bn;
+  wgrad_tile(g, fast, mfma_f16 && pixtab, bm, bn);
   const int wbk = fast ? WBK2 : WBK;
   const int tiles_m = (d.Mtot + bm - 1) / bm, tiles_n = (g->K + bn - 1) / bn;
   const long long blocks = (long long)tiles_m * tiles_n;

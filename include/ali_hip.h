@@ -109,6 +109,10 @@ typedef struct {
    * out_ld = the same for the output (and dact_y, out16).  0 = dense.  Not with the fused BatchNorm modes. */
   int32_t in_ld;
   int32_t out_ld;
+  /* Forward convs: the number of leading input channels that carry data when the channel stride is padded (a first
+   * layer's 5 planes in an 8-channel NHWC tensor, mnist.py:108); the others must be zero in x or in w_kxc.  A hint:
+   * 0 = unknown; kernels that can skip the padding do. */
+  int32_t in_ch_live;
 } AliEpilogue;
 
 /* A weight-gradient launch that splits the pixel range writes S partial results ("slabs") into its workspace and
@@ -185,6 +189,9 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
 /* Launches deferred weight-gradient GEMMs (jobs[i].opaque[0] == 1 each) together, 12 per launch, longest blocks first.
  * Every operand and workspace region named at ali_conv_bwd_weight time must still be alive and unchanged. */
 int ali_wgrad_launch_multi(int32_t n, const AliWgradJob* jobs, ali_stream_t stream);
+/* 1 if ali_conv_bwd_weight would defer the launch for this geometry when given a job (pixel table present): lets the
+ * caller count a pass's jobs -- and so choose split_target -- before the first launch. */
+int32_t ali_wgrad_deferrable(const AliConvGeom* g, int32_t mfma_f16);
 /* Folds the slabs of up to any number of deferred weight-gradient launches (jobs[i].S > 0 each) in as few launches as
  * possible (12 jobs per launch), writing every dst / db. */
 int ali_wgrad_fold_multi(int32_t n, const AliWgradFold* jobs, ali_stream_t stream);

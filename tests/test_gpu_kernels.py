@@ -55,6 +55,7 @@ CONV_CASES = [
     (1, 3, 37, 8, 5, 2, 1),
     (512, 256, 3, 512, 4, 2, 1),   # split-K path at the bench batch
     (70, 5, 28, 32, 5, 1, 0), (64, 7, 20, 32, 3, 1, 0),   # per-image first-layer kernel (B >= 64, 8 -> 32 channels)
+    (64, 5, 9, 32, 5, 1, 0), (130, 8, 12, 32, 5, 1, 0),
 ]
 
 
@@ -79,6 +80,14 @@ def test_conv2d_fwd_bwd(B, C, H, K, R, stride, pad):
     y = torch.empty(B, P, P, K, device="cuda")
     ops.conv_fwd(geom, xh, pack_conv_fwd(ops, w, cpad), y, ops.epilogue(bias=b.cuda(), act=ops.ACT_LEAKY, slope=0.2))
     close(nchw(y), yr, what="fwd")
+    if cpad != C:   # the live-channel hint (AliEpilogue.in_ch_live): padding channels are skipped where a kernel can
+        ep = ops.epilogue(bias=b.cuda(), act=ops.ACT_LEAKY, slope=0.2)
+        ep.in_ch_live = C
+        wp = pack_conv_fwd(ops, w, cpad).clone()
+        wp[..., C:] = 7.0          # weights of the (zero) padding channels must not matter
+        y2 = torch.full_like(y, float("nan"))
+        ops.conv_fwd(geom, xh, wp, y2, ep)
+        close(nchw(y2), yr, what="fwd, live-channel hint")
     # backward: act', bias grad, data grad, weight grad
     gpre = ops.act_bwd(nhwc(gy).cuda(), y, ops.ACT_LEAKY, 0.2)
     db = ops.colsum(B * P * P, K, K, gpre)
