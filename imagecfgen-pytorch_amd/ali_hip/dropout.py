@@ -104,7 +104,7 @@ def peek_mask(skip: int, B: int, C: int, p: float, device, cpad=None):
     inj = _state["inject"]
     if inj is not None:
         i = _state["pos"] + skip
-        if i + _state["pair"] >= len(inj) + (0 if _state["pair"] else 1):
+        if i + _state["pair"] >= len(inj):
             return None
         m = inj[i]
         if _state["pair"]:

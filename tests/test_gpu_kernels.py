@@ -366,6 +366,110 @@ def test_cost_ordered_dispatch_is_a_pure_reordering(kind, B, C, H, K, R, stride,
     assert not torch.isnan(outs[0][0]).any()
 
 
+@pytest.mark.parametrize("B,C,K,R,H", [(96, 64, 128, 1, 1), (64, 256, 512, 3, 3)])
+def test_column_range_operands(B, C, K, R, H):
+    """AliEpilogue.in_ld / out_ld and dy_ld: operands that are column ranges of wider row-major buffers (D's joint
+    [dx | dz] rows, mnist.py:152-154) give exactly what dense copies of them give -- forward output (+ mask) into a
+    column range, data gradient and weight gradient (+ fused bias gradient) from one."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    T = R * R
+    x = torch.randn(B, H, H, C, device="cuda", generator=g)
+    w = torch.randn(K, T, C, device="cuda", generator=g) / (C * T) ** 0.5
+    wd = torch.randn(C, T, K, device="cuda", generator=g) / (K * T) ** 0.5
+    bias = torch.randn(K, device="cuda", generator=g)
+    geom = ops.geom(B, H, H, C, 1, 1, K, R, R, 1, 0)
+    ld, off = K + 96, 32
+    wide = torch.full((B, ld), 3.0, device="cuda")
+    mask_w = (torch.rand(B, ld, device="cuda", generator=g) > 0.3).float() * 1.25
+    # forward: act(conv + bias) * mask into columns [off, off + K)
+    ref = torch.empty(B, 1, 1, K, device="cuda")
+    ops.conv_fwd(geom, x, w, ref, ops.epilogue(bias=bias, act=ops.ACT_LEAKY, slope=0.1,
+                                               mask=mask_w[:, off:off + K].contiguous()))
+    ep = ops.epilogue(bias=bias, act=ops.ACT_LEAKY, slope=0.1)
+    ep.mask, ep.mask_ld = mask_w[:, off:off + K].data_ptr(), ld
+    ops.conv_fwd(geom, x, w, wide[:, off:off + K].unflatten(1, (1, 1, K)), ep, out_ld=ld)
+    assert torch.equal(wide[:, off:off + K], ref.reshape(B, K))
+    assert (wide[:, :off] == 3.0).all() and (wide[:, off + K:] == 3.0).all()
+    # backward from a column range
+    gw = torch.randn(B, ld, device="cuda", generator=g)
+    gd = gw[:, off:off + K].contiguous().reshape(B, 1, 1, K)
+    gv = gw[:, off:off + K].unflatten(1, (1, 1, K))
+    dx1, dx2 = torch.empty(B, H, H, C, device="cuda"), torch.empty(B, H, H, C, device="cuda")
+    ops.conv_bwd_data(geom, gd, wd, dx1, ops.epilogue())
+    ops.conv_bwd_data(geom, gv, wd, dx2, ops.epilogue(), in_ld=ld)
+    assert torch.equal(dx1, dx2)
+    dw1, dw2 = torch.empty(K, C, R, R, device="cuda"), torch.empty(K, C, R, R, device="cuda")
+    db1, db2 = torch.empty(K, device="cuda"), torch.empty(K, device="cuda")
+    ops.conv_bwd_weight(geom, x, gd, dw1, C, K, C * T, T, 1, db=db1)
+    ops.conv_bwd_weight(geom, x, gv, dw2, C, K, C * T, T, 1, db=db2, dy_ld=ld)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+def test_deferred_weight_gradients_match_their_own_launches():
+    """ops.FoldQueue: three weight gradients recorded (AliWgradJob / AliWgradFold) and issued as one multi-job GEMM
+    launch + one multi-job slab fold == the same three launched one by one (same pixel split: bit-identical), incl. the
+    fused bias gradient; a job's operands may be freed by the caller before the flush (the queue keeps them)."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cases = [(512, 1, 1024, 1024, 1, 1, 0), (512, 8, 128, 256, 4, 2, 0), (512, 3, 256, 512, 3, 1, 0)]
+    q = ops.FoldQueue(torch.device("cuda", 0))
+    geoms, outs, refs = [], [], []
+    for (B, H, C, K, R, st, pad) in cases:
+        P = (H + 2 * pad - R) // st + 1
+        geoms.append(ops.geom(B, H, H, C, P, P, K, R, R, st, pad))
+    q.expect(geoms)
+    target = q.split_target()
+    assert target == 682
+    import os
+    import ali_hip
+    try:
+        for (B, H, C, K, R, st, pad), geom in zip(cases, geoms):
+            P = geom.P
+            x = torch.randn(B, H, H, C, device="cuda", generator=g)
+            dy = torch.randn(B, P, P, K, device="cuda", generator=g)
+            dw, db = torch.full((K, C, R, R), float("nan"), device="cuda"), torch.full((K,), float("nan"), device="cuda")
+            ops.conv_bwd_weight(geom, x, dy, dw, C, K, C * R * R, R * R, 1, db=db, defer=q)
+            outs.append((dw, db))
+            os.environ["ALI_WGRAD_BLOCKS"] = str(target)        # the stand-alone launch with the same pixel split
+            ali_hip.load().ali_reload_tuning()
+            dwr, dbr = torch.empty(K, C, R, R, device="cuda"), torch.empty(K, device="cuda")
+            ops.conv_bwd_weight(geom, x, dy, dwr, C, K, C * R * R, R * R, 1, db=dbr)
+            os.environ.pop("ALI_WGRAD_BLOCKS")
+            ali_hip.load().ali_reload_tuning()
+            refs.append((dwr, dbr))
+            del x, dy
+        assert len(q.launches) == 3 and len(q.jobs) == 3 and torch.isnan(outs[0][0]).all()
+        q.flush()
+    finally:
+        os.environ.pop("ALI_WGRAD_BLOCKS", None)
+        ali_hip.load().ali_reload_tuning()
+    for (dw, db), (dwr, dbr) in zip(outs, refs):
+        assert torch.equal(dw, dwr) and torch.equal(db, dbr)
+
+
+def test_copy_multi_and_mask_peek():
+    ops = _ops()
+    from ali_hip import dropout
+    src = [torch.randn(512, 784, device="cuda"), torch.arange(512, device="cuda", dtype=torch.int64),
+           torch.randn(3, device="cuda"), torch.randn(512, 1, device="cuda").double()]
+    dst = [torch.zeros_like(t) for t in src]
+    strided = torch.randn(8, 6, device="cuda")[:, ::2]
+    dst_s = torch.zeros(8, 3, device="cuda")
+    ops.copy_multi(list(zip(dst, src)) + [(dst_s, strided)])
+    assert all(torch.equal(d, t) for d, t in zip(dst, src)) and torch.equal(dst_s, strided)
+    # peek_mask: the mask a later request will return, without consuming it (injected tape, paired passes)
+    tape = [torch.rand(4, 8) for _ in range(6)]
+    with dropout.injected_masks(tape):
+        assert torch.equal(dropout.peek_mask(2, 4, 8, 0.5, torch.device("cuda")).cpu(), tape[2])
+        assert dropout.peek_mask(2, 4, 9, 0.5, torch.device("cuda")) is None      # not the request that will come
+        assert dropout.peek_mask(6, 4, 8, 0.5, torch.device("cuda")) is None
+        assert torch.equal(dropout.next_mask(4, 8, 0.5, torch.device("cuda")).cpu(), tape[0])
+        with dropout.paired_passes(3):
+            both = dropout.peek_mask(1, 8, 8, 0.5, torch.device("cuda")).cpu()
+            assert torch.equal(both, torch.cat([tape[2], tape[5]]))
+
+
 def test_splitk_last_block_fold_stress():
     """The in-kernel split-K fold (slabs written and read with device-scope accesses, per-tile arrival counters) under
     back-to-back launches that reuse the same slabs with different data: a stale slab or a counter left non-zero
