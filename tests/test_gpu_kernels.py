@@ -81,7 +81,8 @@ def test_conv2d_fwd_bwd(B, C, H, K, R, stride, pad):
     ops.conv_fwd(geom, xh, pack_conv_fwd(ops, w, cpad), y, ops.epilogue(bias=b.cuda(), act=ops.ACT_LEAKY, slope=0.2))
     close(nchw(y), yr, what="fwd")
     if cpad != C:   # the live-channel hint (AliEpilogue.in_ch_live): padding channels are skipped where a kernel can
-        ep = ops.epilogue(bias=b.cuda(), act=ops.ACT_LEAKY, slope=0.2)
+        bc = b.cuda()               # (the epilogue holds raw pointers: the tensor must outlive the launch)
+        ep = ops.epilogue(bias=bc, act=ops.ACT_LEAKY, slope=0.2)
         ep.in_ch_live = C
         wp = pack_conv_fwd(ops, w, cpad).clone()
         wp[..., C:] = 7.0          # weights of the (zero) padding channels must not matter
