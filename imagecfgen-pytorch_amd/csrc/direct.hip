@@ -15,10 +15,6 @@
 
 namespace ali {
 
-constexpr int T1_RB = 8;    // output rows per block (fwd)
-constexpr int T1_CB = 32;   // output cols per block (fwd)
-constexpr int T1_KC = 16;   // channels staged per pass
-constexpr int T1_LDP = 20;  // padded pixel stride in floats (80 B): conflict-free ds_read_b128 across pixels
 
 struct T1Desc {
   const float* big;
@@ -40,86 +36,108 @@ struct T1Desc {
 };
 
 // ---------------------------------------------------------------- forward: big (K ch) -> small (1 ch)
+// Block = T1F_RB x T1F_CB output pixels of one image; 32 channels of the (halo'd) big patch are staged in LDS per pass.
+// A thread owns 4 channels (k4 = thread % 8) of a run of 4 output pixels: the filter taps of its channels sit in
+// registers (TAPS x 4 floats), a filter row costs 4+S-1 reads of the patch for 4*S*4 fma (10 fma per LDS read instead
+// of 2 with one pixel per thread: that kernel was LDS-bandwidth bound at 0.9 TB/s of input), and the 8 channel lanes
+// of a pixel run meet in three shuffles.
+constexpr int T1F_RB = 4, T1F_CB = 32, T1F_KC = 32, T1F_LDP = T1F_KC + 4;
+template <int TAPS, int S_>
 __global__ __launch_bounds__(256) void tconv1_fwd_kernel(const T1Desc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int PR = T1_RB + d.R - 1, PC = T1_CB + d.S - 1;  // staged patch of big pixels
-  float* patch = smem;                                    // [PR*PC][T1_LDP]
-  float* wl = smem + PR * PC * T1_LDP;                    // [R*S][K]
+  constexpr int R_ = TAPS / S_;
+  constexpr int PR = T1F_RB + R_ - 1, PC = T1F_CB + S_ - 1;   // staged patch of big pixels
+  float* patch = smem;                                      // [PR*PC][T1F_LDP]
   const int t = threadIdx.x;
-  const int T = d.R * d.S;
   const int b = blockIdx.z;
-  const int h0 = blockIdx.y * T1_RB, w0 = blockIdx.x * T1_CB;
-  for (int i = t; i < T * d.K; i += 256) wl[i] = d.w[i];
-  const int ty = t / T1_CB, tx = t % T1_CB;
-  const int h = h0 + ty, wq = w0 + tx;
+  const int h0 = blockIdx.y * T1F_RB, w0 = blockIdx.x * T1F_CB;
   // patch origin in the big map: row = h0 + pad - (R-1), col = w0 + pad - (S-1)
-  const int pr0 = h0 + d.pad - (d.R - 1), pc0 = w0 + d.pad - (d.S - 1);
-  float acc = 0.f;
-  for (int kc = 0; kc < d.K; kc += T1_KC) {
+  const int pr0 = h0 + d.pad - (R_ - 1), pc0 = w0 + d.pad - (S_ - 1);
+  const int k4 = t & 7, grp = t >> 3;                       // 32 groups = T1F_RB rows x 8 runs of 4 pixels
+  const int gy = grp >> 3, gx = (grp & 7) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < d.K; kc += T1F_KC) {
     __syncthreads();
-    for (int i = t; i < PR * PC * (T1_KC / 4); i += 256) {
-      const int c4 = i % (T1_KC / 4);
-      const int pix = i / (T1_KC / 4);
-      const int pr = pix / PC, pc = pix % PC;
+    for (int i = t; i < PR * PC * (T1F_KC / 4); i += 256) {
+      const int c4 = i % (T1F_KC / 4);
+      const int pix = i / (T1F_KC / 4);
+      const int pr = pix / PC, pc = pix - pr * PC;
       const int ih = pr0 + pr, iw = pc0 + pc;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)ih < (unsigned)d.P && (unsigned)iw < (unsigned)d.Q && kc + c4 * 4 < d.K)
+      if ((unsigned)ih < (unsigned)d.P && (unsigned)iw < (unsigned)d.Q)
         v = *reinterpret_cast<const f32x4*>(d.big + ((long long)(b * d.P + ih) * d.Q + iw) * d.K + kc + c4 * 4);
-      *reinterpret_cast<f32x4*>(patch + pix * T1_LDP + c4 * 4) = v;
+      *reinterpret_cast<f32x4*>(patch + pix * T1F_LDP + c4 * 4) = v;
     }
-    __syncthreads();
-    if (ty < T1_RB) {
-      for (int r = 0; r < d.R; ++r) {
-        const float* prow = patch + ((ty + d.R - 1 - r) * PC + tx + d.S - 1) * T1_LDP;
-        const float* wrow = wl + (r * d.S) * d.K + kc;
-        for (int s = 0; s < d.S; ++s) {
-          const float* pp = prow - s * T1_LDP;
-          const float* ww = wrow + s * d.K;
+    f32x4 wr[TAPS];
 #pragma unroll
-          for (int c4 = 0; c4 < T1_KC / 4; ++c4) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(pp + c4 * 4);
-            const f32x4 y = *reinterpret_cast<const f32x4*>(ww + c4 * 4);
-            acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
-          }
-        }
-      }
+    for (int tp = 0; tp < TAPS; ++tp) wr[tp] = *reinterpret_cast<const f32x4*>(d.w + tp * d.K + kc + k4 * 4);
+    __syncthreads();
+    f32x4 a4[4];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) a4[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < R_; ++r) {
+      // output (gy, gx+px), tap (r, s) reads patch row gy + R-1-r, column gx + px + S-1-s
+      const float* prow = patch + ((gy + R_ - 1 - r) * PC + gx) * T1F_LDP + k4 * 4;
+      f32x4 xv[4 + S_ - 1];
+#pragma unroll
+      for (int c = 0; c < 4 + S_ - 1; ++c) xv[c] = *reinterpret_cast<const f32x4*>(prow + c * T1F_LDP);
+#pragma unroll
+      for (int s = 0; s < S_; ++s)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) a4[px] += xv[px + S_ - 1 - s] * wr[r * S_ + s];
     }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) acc[px] += (a4[px][0] + a4[px][1]) + (a4[px][2] + a4[px][3]);
   }
-  if (ty < T1_RB && h < d.H && wq < d.W) {
-    float v = acc + (d.bias ? d.bias[0] : 0.f);
-    v = apply_act(v, d.act, d.slope);
-    if (d.rowscale) v *= d.rowscale[(long long)b * d.rowscale_ld];
-    d.out[((long long)(b * d.H + h) * d.W + wq) * d.ostride] = v;
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    float v = acc[px];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    acc[px] = v;
+  }
+  if (k4 == 0) {
+    const int h = h0 + gy;
+    const float bias = d.bias ? d.bias[0] : 0.f;
+    const float rs = d.rowscale ? d.rowscale[(long long)b * d.rowscale_ld] : 1.f;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const int wq = w0 + gx + px;
+      if (h < d.H && wq < d.W)
+        d.out[((long long)(b * d.H + h) * d.W + wq) * d.ostride] = apply_act(acc[px] + bias, d.act, d.slope) * rs;
+    }
   }
 }
 
 // ---------------------------------------------------------------- data gradient: small (1 ch) -> big (K ch)
+// One thread owns 4 channels (k4 = thread % (K/4): the grid stride is a multiple of K/4) and keeps their filter taps in
+// registers (TAPS x 4 floats), so an output costs TAPS scalar reads of the 1-channel map and 4*TAPS fma -- no LDS traffic
+// in the loop; the kernel then moves at the rate of its 4*K-byte output rows (+ the act' operand).
+template <int TAPS>
 __global__ __launch_bounds__(256) void tconv1_dgrad_kernel(const T1Desc d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wl = smem;  // [R*S][K]
-  const int T = d.R * d.S;
-  for (int i = threadIdx.x; i < T * d.K; i += 256) wl[i] = d.w[i];
-  __syncthreads();
   const int K4 = d.K / 4;
+  const int k4 = threadIdx.x % K4;
+  f32x4 wr[TAPS];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) wr[tp] = *reinterpret_cast<const f32x4*>(d.w + tp * d.K + k4 * 4);
   const long long total = (long long)d.B * d.P * d.Q * K4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int k4 = (int)(i % K4);
     const long long pix = i / K4;
     const int q = (int)(pix % d.Q);
     const long long t2 = pix / d.Q;
     const int p = (int)(t2 % d.P);
     const int b = (int)(t2 / d.P);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < d.R; ++r) {
-      const int ih = p + r - d.pad;
-      if ((unsigned)ih >= (unsigned)d.H) continue;
-      for (int s = 0; s < d.S; ++s) {
-        const int iw = q + s - d.pad;
-        if ((unsigned)iw >= (unsigned)d.W) continue;
-        const float g = d.small[((long long)(b * d.H + ih) * d.W + iw) * d.sstride];
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (r * d.S + s) * d.K + k4 * 4);
-        a += g * wv;
-      }
+    const float* sb = d.small + (long long)b * d.H * d.W * d.sstride;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const int r = tp / d.S, s = tp - r * d.S;
+      const int ih = p + r - d.pad, iw = q + s - d.pad;
+      const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+      const float g = ok ? sb[(long long)(ih * d.W + iw) * d.sstride] : 0.f;
+      a += g * wr[tp];
     }
     const long long o = pix * d.K + k4 * 4;
     if (d.dact_y) {
@@ -317,9 +335,16 @@ extern "C" int ali_tconv1_fwd(const float* big, const float* w_tk, const float* 
   d.B = B; d.P = P; d.Q = Q; d.K = K; d.H = H; d.W = W; d.R = R; d.S = S; d.pad = pad;
   d.ostride = ostride; d.act = act; d.slope = slope;
   d.rowscale = rowscale; d.rowscale_ld = rowscale_ld;
-  const size_t lds = ((size_t)(T1_RB + R - 1) * (T1_CB + S - 1) * T1_LDP + (size_t)R * S * K) * sizeof(float);
-  dim3 grid((W + T1_CB - 1) / T1_CB, (H + T1_RB - 1) / T1_RB, B);
-  hipLaunchKernelGGL(tconv1_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, d);
+  if ((K % T1F_KC) != 0 || R != S) { set_error("ali_tconv1_fwd: needs K %% 32 == 0 and a square kernel"); return ALI_ERR_BAD_ARG; }
+  const size_t lds = (size_t)(T1F_RB + R - 1) * (T1F_CB + S - 1) * T1F_LDP * sizeof(float);
+  dim3 grid((W + T1F_CB - 1) / T1F_CB, (H + T1F_RB - 1) / T1F_RB, B);
+#define T1F(T_, S__) hipLaunchKernelGGL((tconv1_fwd_kernel<T_, S__>), grid, dim3(256), lds, (hipStream_t)stream, d)
+  if (R == 5) T1F(25, 5);
+  else if (R == 4) T1F(16, 4);
+  else if (R == 3) T1F(9, 3);
+  else if (R == 2) T1F(4, 2);
+  else T1F(1, 1);
+#undef T1F
   return check_launch("tconv1_fwd_kernel");
 }
 
@@ -336,8 +361,16 @@ extern "C" int ali_tconv1_dgrad(const float* small, int32_t sstride, const float
   const long long total = (long long)B * P * Q * (K / 4);
   long long nb = (total + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(tconv1_dgrad_kernel, dim3((int)nb), dim3(256), (size_t)R * S * K * sizeof(float),
-                     (hipStream_t)stream, d);
+  if (256 % (K / 4) != 0) { set_error("ali_tconv1_dgrad: K/4 must divide 256"); return ALI_ERR_BAD_ARG; }
+  const int T = R * S;
+#define T1D(T_) hipLaunchKernelGGL(tconv1_dgrad_kernel<T_>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, d)
+  if (T == 16) T1D(16);
+  else if (T == 25) T1D(25);
+  else if (T == 9) T1D(9);
+  else if (T == 4) T1D(4);
+  else if (T == 1) T1D(1);
+  else { set_error("ali_tconv1_dgrad: unsupported kernel size %dx%d", R, S); return ALI_ERR_BAD_ARG; }
+#undef T1D
   return check_launch("tconv1_dgrad_kernel");
 }
 
