@@ -433,7 +433,9 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             ep.mask, ep.mask_ld = jmask.data_ptr(), jmask.stride(0)
         if si == 0 and st.kind == "conv" and c_log < Cp:
             ep.in_ch_live = c_log          # channel padding of a first layer: kernels that can skip it do
-        if _scatter_fwd(st, Cp) and folded is None:    # (measured 12 us faster than tconv1_fwd on the MNIST tail, too)
+        # (the register-blocked tconv1_fwd beats the scatter form on the MNIST tail by 17 us per launch; the scatter
+        # form serves the stride-2 / two-channel tails of the spectrogram Generators)
+        if _scatter_fwd(st, Cp) and folded is None and not _is_tconv1(st, Cp):
             m = st.mod
             R, S = m.kernel_size
             Co = m.out_channels

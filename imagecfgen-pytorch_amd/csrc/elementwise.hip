@@ -837,6 +837,17 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
     // nearest: src = floor(dst * 16 / size)  (torch 'nearest', probe-verified in SURVEY.md K8)
     const int sh = (int)(((long long)h * 16) / H), sw = (int)(((long long)w * 16) / W);
     float* o = out + i * Cpad;
+    if (Cpad == 8) {                     // the MNIST stacks' 5 planes in 8 channels: two 16-byte stores per pixel
+      float v[8];
+      v[0] = X[i];
+      int c = 1;
+      for (int j = 0; j < n_emb; ++j, ++c) v[c] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + sh * 16 + sw]);
+      for (int j = 0; j < n_cont; ++j, ++c) v[c] = cont[b * n_cont + j];
+      for (; c < 8; ++c) v[c] = 0.f;
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      continue;
+    }
     o[0] = X[i];
     int c = 1;
     for (int j = 0; j < n_emb; ++j, ++c) o[c] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + sh * 16 + sw]);
