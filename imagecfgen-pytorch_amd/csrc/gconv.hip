@@ -1388,7 +1388,44 @@ extern "C" int32_t ali_conv_tile_order(const AliConvGeom* g, int32_t which, int3
   std::vector<int> idx(tiles);
   for (int i = 0; i < tiles; ++i) idx[i] = i;
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-  for (int i = 0; i < tiles; ++i) order[i] = idx[i];
+  // The blocks that are resident when the launch starts (the first 4 * CUs slots) stay where the dispatcher puts them:
+  // slot u on CU u % CUs.  Handing the sorted tiles out in slot order gives CU c the c-th heaviest tile of EVERY
+  // quartile, i.e. CU 0 the heaviest four (34 taps against a mean of 26 on D's 4x4 stride-1 data gradient).  Instead:
+  // longest-processing-time-first onto the CUs -- each tile, heaviest first, goes to the free rank position whose
+  // CUs carry the least so far.  Tiles beyond the resident window follow in sorted order (they are dispatched as
+  // blocks retire).  Grids whose left-over tiles are split along K keep the plain order (their last slots are special).
+  const int nt = (d.Cout + tc.bn - 1) / tc.bn;
+  const long long blocks = (long long)tiles * nt;
+  bool tail_split = false;
+  if (blocks > kNumCU && blocks < 4 * kNumCU) {
+    const int R = (int)(blocks % kNumCU);
+    const int max_nkt = (max_taps * d.Cin + BK - 1) / BK;
+    tail_split = R > 0 && 2 * R <= kNumCU && max_nkt / 2 >= 4;
+  }
+  const int W = std::min(tiles, 4 * kNumCU / nt);
+  if (tail_split || W < 2) {
+    for (int i = 0; i < tiles; ++i) order[i] = idx[i];
+    return tiles;
+  }
+  const int full = (tiles / 8) * 8;
+  auto slot_of = [&](int r, int by) { return r < full ? (r / 8) * 8 * nt + by * 8 + (r % 8) : full * nt + (r - full) * nt + by; };
+  std::vector<long long> load(kNumCU, 0);
+  std::vector<char> used(W, 0);
+  for (int i = 0; i < W; ++i) {
+    const int tile = idx[i];
+    int best = -1;
+    long long best_load = 0;
+    for (int p = 0; p < W; ++p) {
+      if (used[p]) continue;
+      long long l = 0;
+      for (int by = 0; by < nt; ++by) l = std::max(l, load[slot_of(p, by) % kNumCU]);
+      if (best < 0 || l < best_load) { best = p; best_load = l; }
+    }
+    used[best] = 1;
+    order[best] = tile;
+    for (int by = 0; by < nt; ++by) load[slot_of(best, by) % kNumCU] += cost[tile];
+  }
+  for (int i = W; i < tiles; ++i) order[i] = idx[i];
   return tiles;
 }
 

@@ -296,9 +296,9 @@ def test_spectrogram_front_end_vs_torch_stft(n_fft, win, hop, pad, L):
     ("fwd", 512, 128, 13, 256, 3, 2, 1), ("fwd", 192, 64, 14, 128, 4, 2, 1), ("dgrad", 576, 128, 13, 256, 3, 2, 1)])
 def test_cost_ordered_dispatch_is_a_pure_reordering(kind, B, C, H, K, R, stride, pad):
     """ali_conv_tile_order: launches whose M-tiles have different k-loop lengths (padding / strided transposed taps
-    skipped tile-wide) dispatch the long tiles first.  The table is a permutation sorted by the number of live taps,
-    and the launch computes bit-identical results with and without it (incl. tail-split grids and the fused
-    BatchNorm partial sums, whose slots are indexed by the logical tile)."""
+    skipped tile-wide) are dispatched in a cost-aware order (tests/test_host_cpu.py checks the balance it achieves).
+    The table is a permutation of the M-tiles, and the launch computes bit-identical results with and without it
+    (incl. tail-split grids and the fused BatchNorm partial sums, whose slots are indexed by the logical tile)."""
     import ctypes
     import os
     import ali_hip
@@ -310,32 +310,6 @@ def test_cost_ordered_dispatch_is_a_pure_reordering(kind, B, C, H, K, R, stride,
     n = ali_hip.load().ali_conv_tile_order(ctypes.byref(geom), which, 0, ctypes.cast(buf, ctypes.c_void_p), 65536)
     tiles, rows, pm = ops.conv_mtiles(geom, which)
     assert n == tiles and pm and sorted(buf[:n]) == list(range(n))
-    # live taps of a tile's pixel position, recomputed here
-    def taps(tile):
-        if kind == "fwd":
-            pix = tile * rows // B
-            qh, qw = divmod(pix, P)
-            vh = sum(0 <= qh * stride - pad + r < H for r in range(R))
-            vw = sum(0 <= qw * stride - pad + r < H for r in range(R))
-            return vh * vw
-        # data gradient: phases (oh % stride, ow % stride) in order, each a (pixel, image) raster of its sub-grid
-        t0 = 0
-        for ph in range(stride):
-            for pw in range(stride):
-                Hq, Wq = (H - ph + stride - 1) // stride, (H - pw + stride - 1) // stride
-                nt = (B * Hq * Wq + rows - 1) // rows
-                if tile < t0 + nt:
-                    pix = (tile - t0) * rows // B
-                    qh, qw = divmod(pix, Wq)
-                    oh, ow = ph + qh * stride, pw + qw * stride
-                    vh = sum((oh + pad - r) % stride == 0 and 0 <= (oh + pad - r) // stride < P for r in range(R))
-                    vw = sum((ow + pad - r) % stride == 0 and 0 <= (ow + pad - r) // stride < P for r in range(R))
-                    return vh * vw
-                t0 += nt
-        raise AssertionError(tile)
-    if B % rows == 0:
-        costs = [taps(t) for t in buf[:n]]
-        assert costs == sorted(costs, reverse=True) and costs[0] > costs[-1]
     g = torch.Generator(device="cuda").manual_seed(3)
     T = R * R
     if kind == "fwd":

@@ -25,10 +25,11 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.ali_version() >= 1
 
 
-def test_tile_order_is_host_side_and_sorted_by_live_taps():
-    """ali_conv_tile_order runs on the host (no GPU): a permutation of the M-tiles of MNIST D's 256 -> 128 4x4 stride-2
-    data gradient (mnist.py:120) with the 16 interior pixel positions (4 live taps) first and the corners last; layers
-    whose tiles all cost the same report 0."""
+def test_tile_order_is_host_side_and_balances_the_cus():
+    """ali_conv_tile_order runs on the host (no GPU).  MNIST D's 256 -> 128 4x4 stride-2 data gradient (mnist.py:120): 512
+    M-tiles x 2 n-tiles = 1024 blocks, all resident, 4 per CU, with 1, 2 or 4 live taps per tile.  Slot u runs on CU
+    u % 256; the table places the tiles so that every CU gets the same number of taps (9 x 2 n-tiles); in raster
+    order a CU would hold four neighbouring tiles (up to 16 x 2).  Layers whose tiles all cost the same report 0."""
     import ctypes
     import ali_hip
     from ali_hip import ops
@@ -44,8 +45,16 @@ def test_tile_order_is_host_side_and_sorted_by_live_taps():
         oh, ow = (ph // 2) + 2 * qh, (ph % 2) + 2 * qw
         cnt = lambda o: sum((o - r) % 2 == 0 and 0 <= (o - r) // 2 < 3 for r in range(4))      # noqa: E731
         return cnt(oh) * cnt(ow)
-    costs = [live(t) for t in buf[:n]]
-    assert costs == sorted(costs, reverse=True) and costs[:128] == [4] * 128 and costs[-128:] == [1] * 128
+
+    def cu_loads(order):    # the kernel's slot -> (rank, n-tile) map (n-tiles of a rank 8 slots apart), slot u on CU u % 256
+        load = [0] * 256
+        for u in range(1024):
+            grp, rem = divmod(u, 16)
+            load[u % 256] += live(order[grp * 8 + (rem & 7)])
+        return load
+    assert sorted(live(t) for t in range(512)) == [1] * 128 + [2] * 256 + [4] * 128
+    balanced, raster = cu_loads(list(buf[:n])), cu_loads(list(range(512)))
+    assert max(balanced) == min(balanced) == 9 and max(raster) == 16
     g1 = ops.geom(512, 1, 1, 1024, 1, 1, 1024, 1, 1, 1, 0)
     assert lib.ali_conv_tile_order(ctypes.byref(g1), 0, 0, ctypes.cast(buf, ctypes.c_void_p), 4096) == 0
     assert lib.ali_conv_tile_order(ctypes.byref(g), 1, 0, ctypes.cast(buf, ctypes.c_void_p), 100) == 0   # cap too small
