@@ -95,10 +95,10 @@ SIGNATURES = {
     "ali_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                            c_int32, c_void_p, c_float, c_void_p]),
     "ali_assemble_planes": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_int32, c_void_p,
-                                      c_int32, c_int32, c_int32, c_int32, c_void_p]),
+                                      c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "ali_spect_post": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "ali_plane_table_grad": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32,
-                                       c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+                                       c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "ali_col2im": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 12 + [c_float, c_void_p]),
     "ali_tconv1_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_float, c_void_p, c_int32,
                                                                                             c_void_p]),

@@ -677,18 +677,20 @@ def bn_bwd(x, g, mask_in, mask_pre, st, gamma, B, rows_per_img, C, batch_stats, 
     return out_dgamma, out_dbeta, gx
 
 
-def plane_table_grad(g, g_ch, x0, x_ch, idx, idx_col, n_rows, out=None):
+def plane_table_grad(g, g_ch, x0, x_ch, idx, idx_col, n_rows, out=None, table=None):
     """Embedding-table gradient from the gradient ``g`` [B,H,W,Cg] of the assembled planes ``x0`` [B,H,W,Cx]
-    (include/ali_hip.h: ali_plane_table_grad).  Returns / fills ``out`` [n_rows, 256]."""
+    (include/ali_hip.h: ali_plane_table_grad).  Returns / fills ``out`` [n_rows, 256].  ``table`` [n_rows, 256]: take
+    the plane values from the table instead of ``x0`` (which may then be None, or carry a Dropout2d mask)."""
     lib = _lib.load()
     B, H, W, Cg = g.shape
     if out is None:
         out = torch.empty(n_rows, 256, dtype=torch.float32, device=g.device)
     if not (idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()):
         raise ValueError("idx must be a contiguous int32 CUDA tensor")
-    _lib.check(lib.ali_plane_table_grad(_chk(g, "g"), Cg, g_ch, _chk(x0, "x0"), x0.shape[3], x_ch,
+    _lib.check(lib.ali_plane_table_grad(_chk(g, "g"), Cg, g_ch, None if table is not None else _chk(x0, "x0"),
+                                        0 if table is not None else x0.shape[3], x_ch,
                                         c_void_p(idx.data_ptr()), idx.shape[1], idx_col, B, H, W, n_rows, _chk(out, "out"),
-                                        _stream()), "ali_plane_table_grad")
+                                        _opt(table, "table"), _stream()), "ali_plane_table_grad")
     return out
 
 
@@ -791,9 +793,10 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0)
                             step, ds, grad_scale, _stream()), "ali_adam")
 
 
-def assemble_planes(X, idx, tables, cont, B, H, W, Cpad, out=None):
+def assemble_planes(X, idx, tables, cont, B, H, W, Cpad, out=None, mask=None):
     """X [B,H,W] fp32; idx [B,n_emb] int32; tables: list of [n,256] fp32; cont [B,n_cont] or None.
-    ``out``: optional contiguous [B,H,W,Cpad] destination (e.g. one half of a batched-pass buffer)."""
+    ``out``: optional contiguous [B,H,W,Cpad] destination (e.g. one half of a batched-pass buffer).
+    ``mask`` [B, >= Cpad] (any row stride): multiply the planes by it per (sample, channel)."""
     lib = _lib.load()
     if out is None:
         out = torch.empty(B, H, W, Cpad, dtype=torch.float32, device=X.device)
@@ -806,5 +809,6 @@ def assemble_planes(X, idx, tables, cont, B, H, W, Cpad, out=None):
     n_cont = 0 if cont is None else cont.shape[1]
     _lib.check(lib.ali_assemble_planes(_chk(X, "X"), None if idx is None else c_void_p(idx.data_ptr()),
                                        ctypes.cast(arr, ctypes.POINTER(c_void_p)), n_emb, _opt(cont), n_cont,
-                                       _chk(out), B, H, W, Cpad, _stream()), "ali_assemble_planes")
+                                       _chk(out), B, H, W, Cpad, None if mask is None else _ptr(mask),
+                                       0 if mask is None else mask.stride(0), _stream()), "ali_assemble_planes")
     return out

@@ -198,31 +198,51 @@ class AliStepper:
         self._join_skip = sum(1 for pl in (self.pDx, self.pDz) for st in pl.stages if any(k == "drop" for k, _ in st.pre))
 
     # ------------------------------------------------------------------ pieces
-    def _planes(self, X, idx, cont, tables, out=None):
+    def _planes(self, X, idx, cont, tables, out=None, mask=None):
         B = X.shape[0]
         H, W = self.family.hw
         n_log = 1 + len(tables) + (0 if cont is None else cont.shape[1])
         out = ops.assemble_planes(X.reshape(B, H, W), idx, [t.detach() for t in tables], cont, B, H, W,
-                                  (n_log + 3) // 4 * 4, out=out)
+                                  (n_log + 3) // 4 * 4, out=out, mask=mask)
         return out, n_log
 
-    def _planes_pair(self, Xa, Xb, idx, cont, tables):
-        """The conv inputs of two passes that will run as one 2B batch, assembled straight into its two halves."""
+    def _d_input_mask(self, B, device, cont):
+        """The Dropout2d mask in front of D.dx's first conv (mnist.py:118) for a pass that is about to start, looked up
+        ahead of its turn like the join's (None: not known yet, or no such layer) -- assemble_planes then applies it
+        and no mask pass is needed."""
+        st = self.pDx.stages[0]
+        if [k for k, _ in st.pre] != ["drop"]:
+            return None
+        n_log = 1 + len(self.family.d_tables) + (0 if cont is None else cont.shape[1])
+        return _dropout.peek_mask(0, B, n_log, st.pre[0][1], device, (n_log + 3) // 4 * 4)
+
+    def _d_planes(self, X, idx, cont):
+        """D's conv input for one pass: (x0, n_log, whether x0 already carries the first Dropout2d mask)"""
+        mask = self._d_input_mask(X.shape[0], X.device, cont)
+        x0, n_log = self._planes(X, idx, cont, self.family.d_tables, mask=mask)
+        return x0, n_log, mask is not None
+
+    def _d_planes_pair(self, Xa, Xb, idx, cont):
+        """... of two passes that will run as one 2B batch, assembled straight into its two halves (call inside
+        dropout.paired_passes: the mask is the one of the 2B-row request)"""
         B = Xa.shape[0]
         H, W = self.family.hw
+        tables = self.family.d_tables
         n_log = 1 + len(tables) + (0 if cont is None else cont.shape[1])
+        mask = self._d_input_mask(2 * B, Xa.device, cont)
         buf = torch.empty(2 * B, H, W, (n_log + 3) // 4 * 4, dtype=torch.float32, device=Xa.device)
-        self._planes(Xa, idx, cont, tables, out=buf[:B])
-        self._planes(Xb, idx, cont, tables, out=buf[B:])
-        return buf, n_log
+        self._planes(Xa, idx, cont, tables, out=buf[:B], mask=None if mask is None else mask[:B])
+        self._planes(Xb, idx, cont, tables, out=buf[B:], mask=None if mask is None else mask[B:])
+        return buf, n_log, mask is not None
 
-    def _plane_grads(self, g0, x0, idx, tables, dst):
+    def _plane_grads(self, g0, idx, tables, dst):
         """Embedding-table gradients from the gradient of the assembled planes (tiny tensors).  ``g0`` is either the
-        full input gradient [B,H,W,Cpad] or only its embedding planes [B,H,W,len(tables)]."""
+        full input gradient [B,H,W,Cpad] or only its embedding planes [B,H,W,len(tables)].  tanh' comes from the tables
+        themselves (the stored planes may carry a Dropout2d mask)."""
         gofs = 0 if g0.shape[3] == len(tables) else 1
         g0 = g0.contiguous()
         for j, t in enumerate(tables):
-            ops.plane_table_grad(g0, gofs + j, x0, 1 + j, idx, j, t.shape[0], out=dst[id(t)])
+            ops.plane_table_grad(g0, gofs + j, None, 1 + j, idx, j, t.shape[0], out=dst[id(t)], table=t.detach())
 
     def _g_input(self, z, onehots, cont):
         return _g_input(self.family, z, onehots, cont)
@@ -239,17 +259,17 @@ class AliStepper:
             return None
         return torch.empty(B, ctot, dtype=torch.float32, device=device), mask
 
-    def _dx_forward(self, x0, n_log, save, groups=1):
+    def _dx_forward(self, x0, n_log, save, groups=1, x_masked=False):
         """D.dx, writing its end into the joint buffer when the chains can join: (dx_pre, join) for _d_forward"""
         join = self._join_begin(x0.shape[0], x0.device)
         dx_pre = chain_forward(self.pDx, x0, True, n_log, save, groups,
-                               join=None if join is None else (join[0], 0, join[1]))
+                               join=None if join is None else (join[0], 0, join[1]), first_mask_applied=x_masked)
         return dx_pre, join
 
-    def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None, join=None):
+    def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None, join=None, x_masked=False):
         B = x0.shape[0]
         if dx_pre is None:
-            dx_pre, join = self._dx_forward(x0, n_log, save, groups)
+            dx_pre, join = self._dx_forward(x0, n_log, save, groups, x_masked)
         dx, s_dx = dx_pre
         n_dx = dx.shape[-1]
         dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups,
@@ -262,14 +282,13 @@ class AliStepper:
             logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups, first_mask_applied=True)
         return logit.reshape(B, 1), (s_dx, s_dz, s_dxz, n_dx, n_log)
 
-    def _d_forward_pair(self, x0a, zina, x0b, zinb, n_log, save, x0_pair=None):
+    def _d_forward_pair(self, Xa, zina, Xb, zinb, idx, cont, save):
         """D(a) and D(b) with the same weights as ONE batch of 2B samples (rows [0,B) = a): half the launches, and
         the small 1x1 layers see twice the rows.  BatchNorm statistics, running-stat updates and Dropout2d masks stay
         per pass, in the order a, b (chain_forward groups / dropout.paired_passes)."""
-        x0 = x0_pair if x0_pair is not None else torch.cat([x0a, x0b], dim=0)
-        B = x0.shape[0] // 2
         with _dropout.paired_passes(self._n_drop):
-            logit, saved = self._d_forward(x0, n_log, torch.cat([zina, zinb], dim=0), save, 2)
+            x0, n_log, masked = self._d_planes_pair(Xa, Xb, idx, cont)
+            logit, saved = self._d_forward(x0, n_log, torch.cat([zina, zinb], dim=0), save, 2, x_masked=masked)
         return logit, saved
 
     def _d_backward(self, saved, glogit, need_params, need_x, need_z, planes=None):
@@ -327,9 +346,7 @@ class AliStepper:
         gin, g_log = self._g_input(zin, onehots, cont)
         gz, sG = chain_forward(self.pG, gin, True, g_log, True)
         # D(x, E(x)) and D(G(z), z) share the weights: one batch of 2B samples (reference order: real pass first)
-        x0p, _ = self._planes_pair(images, gz, idx, cont, fam.d_tables)
-        logits, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(None, ex.reshape(zin.shape), None, zin, n_log, True,
-                                                                    x0_pair=x0p)
+        logits, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(images, ex.reshape(zin.shape), gz, zin, idx, cont, True)
         # (bce(D_valid, 0) + bce(D_fake, 1)) / 2 and its gradient for both halves: one launch
         l3, gl = ops.bce_logits_pair(logits, B, 0.0, 1.0, 0.5 * self.loss_scale)
         cx["out"]["loss_eg"] = l3[0]
@@ -348,7 +365,7 @@ class AliStepper:
         g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, bool(self._emb_planes), True, dst,
                                   gx_planes=self._emb_planes or None, fold=self._fold)
         if self._emb_planes:
-            self._plane_grads(g_x0e, x0e, idx, fam.e_tables, dst)
+            self._plane_grads(g_x0e, idx, fam.e_tables, dst)
         # ... fake pass: only the image path (dxz -> dx) reaches G
         g_x0f, _ = chain_backward(self.pDx, slice_saved(s_dx, 1, 2), *self._branch_grad(gjoint, B, B, 0, n_dx),
                                   n_log, True, False, gx_planes=(0,), **self._join_out(gjoint))
@@ -398,9 +415,9 @@ class AliStepper:
     def _d_real_pre(self, cx):
         """D.dx on the real batch: independent of the E+G update whose gradients may still be in the all-reduce."""
         fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
-        x0d, n_log = self._planes(images, idx, cont, fam.d_tables)
+        x0d, n_log, masked = self._d_planes(images, idx, cont)
         cx["x0d"], cx["n_log"] = x0d, n_log
-        cx["dx_pre"] = self._dx_forward(x0d, n_log, True)
+        cx["dx_pre"] = self._dx_forward(x0d, n_log, True, x_masked=masked)
 
     def _d_real_rest(self, cx):
         """D gradients on (x, E'(x)) (reference mnist.py:232-235); E' forward only."""
@@ -413,7 +430,7 @@ class AliStepper:
         l, gl = ops.bce_logits(d_valid, 1.0, self.loss_scale)
         cx["out"]["loss_d_real"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
-        self._plane_grads(g_x0, x0d, idx, fam.d_tables, self.opt_d.grad_views)
+        self._plane_grads(g_x0, idx, fam.d_tables, self.opt_d.grad_views)
         cx["ex"] = ex
 
     def _d_fake_pre(self, cx):
@@ -424,19 +441,18 @@ class AliStepper:
     def _d_fake_rest(self, cx):
         """D gradients on (G'(z), z) (reference mnist.py:237-240); G' forward only."""
         fam, idx, cont, zin = self.family, cx["idx"], cx["cont"], cx["zin"]
-        x0f, _ = self._planes(cx["gz"], idx, cont, fam.d_tables)
-        d_fake, sD = self._d_forward(x0f, cx["n_log"], zin, True)
+        x0f, _, masked = self._d_planes(cx["gz"], idx, cont)
+        d_fake, sD = self._d_forward(x0f, cx["n_log"], zin, True, x_masked=masked)
         l, gl = ops.bce_logits(d_fake, 0.0, self.loss_scale)
         cx["out"]["loss_d_fake"] = l[0]
         g_x0, _ = self._d_backward(sD, gl, True, True, False, planes=self._emb_planes)
-        self._plane_grads(g_x0, x0f, idx, fam.d_tables, self.opt_d.grad_views)
+        self._plane_grads(g_x0, idx, fam.d_tables, self.opt_d.grad_views)
 
     def _phase_scores(self, cx, average_bn=True):
         """sigma(D(G(z),z)).mean(), sigma(D(x,E(x))).mean() (reference mnist.py:243-248): forward only, train mode,
         re-using G'(z) and E'(x) of the D phases (the reference recomputes identical values)."""
         fam, images, idx, cont, zin = self.family, cx["images"], cx["idx"], cx["cont"], cx["zin"]
-        x0p, _ = self._planes_pair(cx["gz"], images, idx, cont, fam.d_tables)
-        logits, _ = self._d_forward_pair(None, zin, None, cx["ex"].reshape(zin.shape), cx["n_log"], False, x0_pair=x0p)
+        logits, _ = self._d_forward_pair(cx["gz"], zin, images, cx["ex"].reshape(zin.shape), idx, cont, False)
         s3 = ops.bce_logits_pair(logits, cx["B"], 0.0, 0.0, 1.0, want_grad=False)[0]
         cx["out"]["dg"], cx["out"]["de"] = s3[1], s3[2]
         _dropout.end_iteration()

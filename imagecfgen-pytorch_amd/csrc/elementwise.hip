@@ -579,7 +579,7 @@ constexpr int kPtgMaxChunks = 8;   // B <= 2048
 __global__ void __launch_bounds__(256)
 plane_table_grad_kernel(const float* __restrict__ g, int g_ld, int g_ch, const float* __restrict__ x, int x_ld, int x_ch,
                         const int* __restrict__ idx, int idx_ld, int idx_col, int B, int H, int W, int n_rows,
-                        float* __restrict__ out) {
+                        float* __restrict__ out, const float* __restrict__ table) {
   __shared__ float red[64][4];
   const int cell = blockIdx.x, ch = cell >> 4, cw = cell & 15, t = threadIdx.x, wave = t >> 6;
   // pixels h with floor(h*16/H) == ch:  ceil(ch*H/16) <= h < ceil((ch+1)*H/16)
@@ -594,11 +594,13 @@ plane_table_grad_kernel(const float* __restrict__ g, int g_ld, int g_ch, const f
     cls[c] = -1;
     if (b < B) {
       cls[c] = idx[(long long)b * idx_ld + idx_col];
+      const float pt = table ? tanhf(table[cls[c] * 256 + cell]) : 0.f;   // (every pixel of the cell shows this entry)
       float acc = 0.f;
       for (int h = h0; h < h1; ++h)
         for (int w = w0; w < w1; ++w) {
           const long long pix = ((long long)b * H + h) * W + w;
-          const float p = x[pix * x_ld + x_ch];
+          // the plane value: stored, or recomputed from the table (the stored planes may carry a Dropout2d mask)
+          const float p = table ? pt : x[pix * x_ld + x_ch];
           acc += g[pix * g_ld + g_ch] * (1.f - p * p);
         }
       val[c] = acc;
@@ -825,7 +827,7 @@ __global__ void bce_logits_pair_kernel(const float* __restrict__ logit, int B, f
 struct EmbPtrs { const float* t[8]; };
 __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* __restrict__ idx, EmbPtrs emb, int n_emb,
                                        const float* __restrict__ cont, int n_cont, float* __restrict__ out, int B,
-                                       int H, int W, int Cpad) {
+                                       int H, int W, int Cpad, const float* __restrict__ mask, int mask_ld) {
   const long long npix = (long long)B * H * W;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
@@ -844,6 +846,10 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
       for (int j = 0; j < n_emb; ++j, ++c) v[c] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + sh * 16 + sw]);
       for (int j = 0; j < n_cont; ++j, ++c) v[c] = cont[b * n_cont + j];
       for (; c < 8; ++c) v[c] = 0.f;
+      if (mask) {                        // the Dropout2d in front of the consuming conv, per (sample, channel)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= mask[(long long)b * mask_ld + e];
+      }
       *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
       *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
       continue;
@@ -853,6 +859,8 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
     for (int j = 0; j < n_emb; ++j, ++c) o[c] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + sh * 16 + sw]);
     for (int j = 0; j < n_cont; ++j, ++c) o[c] = cont[b * n_cont + j];
     for (; c < Cpad; ++c) o[c] = 0.f;
+    if (mask)
+      for (c = 0; c < Cpad; ++c) o[c] *= mask[(long long)b * mask_ld + c];
   }
 }
 
@@ -1185,14 +1193,14 @@ extern "C" int ali_bn_bwd_from_partials(const float* part, int32_t slots, const 
 
 extern "C" int ali_plane_table_grad(const float* g, int32_t g_ld, int32_t g_ch, const float* x, int32_t x_ld, int32_t x_ch,
                                     const int32_t* idx, int32_t idx_ld, int32_t idx_col, int32_t B, int32_t H, int32_t W,
-                                    int32_t n_rows, float* out, ali_stream_t stream) {
-  if (!g || !x || !idx || !out || B <= 0 || B > 256 * kPtgMaxChunks || H <= 0 || W <= 0 || n_rows <= 0 || g_ch < 0 ||
-      g_ch >= g_ld || x_ch < 0 || x_ch >= x_ld || idx_col < 0 || idx_col >= idx_ld) {
+                                    int32_t n_rows, float* out, const float* table, ali_stream_t stream) {
+  if (!g || (!x && !table) || !idx || !out || B <= 0 || B > 256 * kPtgMaxChunks || H <= 0 || W <= 0 || n_rows <= 0 || g_ch < 0 ||
+      g_ch >= g_ld || (x && (x_ch < 0 || x_ch >= x_ld)) || idx_col < 0 || idx_col >= idx_ld) {
     set_error("ali_plane_table_grad: bad argument (B <= 2048)");
     return ALI_ERR_BAD_ARG;
   }
   hipLaunchKernelGGL(plane_table_grad_kernel, dim3(256), dim3(256), 0, ST(stream), g, g_ld, g_ch, x, x_ld, x_ch, idx, idx_ld,
-                     idx_col, B, H, W, n_rows, out);
+                     idx_col, B, H, W, n_rows, out, table);
   return check_launch("plane_table_grad_kernel");
 }
 
@@ -1303,7 +1311,7 @@ extern "C" int ali_adam(float* p, const float* g, float* m, float* v, int64_t n,
 
 extern "C" int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* emb_tables, int32_t n_emb,
                                    const float* cont, int32_t n_cont, float* out, int32_t B, int32_t H, int32_t W,
-                                   int32_t Cpad, ali_stream_t stream) {
+                                   int32_t Cpad, const float* mask, int32_t mask_ld, ali_stream_t stream) {
   if (!X || !out || B <= 0 || H <= 0 || W <= 0 || n_emb < 0 || n_emb > 8 || n_cont < 0 || 1 + n_emb + n_cont > Cpad ||
       (n_emb > 0 && (!idx || !emb_tables)) || (n_cont > 0 && !cont)) {
     set_error("ali_assemble_planes: bad argument");
@@ -1313,6 +1321,6 @@ extern "C" int ali_assemble_planes(const float* X, const int32_t* idx, const flo
   for (int j = 0; j < 8; ++j) e.t[j] = j < n_emb ? emb_tables[j] : nullptr;
   const long long npix = (long long)B * H * W;
   hipLaunchKernelGGL(assemble_planes_kernel, dim3(ew_grid(npix)), dim3(kEwBlock), 0, ST(stream), X, idx, e, n_emb, cont, n_cont,
-                     out, B, H, W, Cpad);
+                     out, B, H, W, Cpad, mask, mask_ld);
   return check_launch("assemble_planes_kernel");
 }

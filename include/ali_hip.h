@@ -337,7 +337,8 @@ int ali_g_input_table_grad(const void* onehot, int32_t onehot_is_int, int32_t n_
  * then n_cont broadcast scalars cont[b,j]; remaining channels up to Cpad = 0. */
 int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* emb_tables, int32_t n_emb,
                         const float* cont, int32_t n_cont, float* out, int32_t B, int32_t H, int32_t W,
-                        int32_t Cpad, ali_stream_t stream);
+                        int32_t Cpad, const float* mask /* optional [B][mask_ld]: out[b,..,c] *= mask[b][c], the
+                        Dropout2d in front of the consuming conv (mnist.py:118) */, int32_t mask_ld, ali_stream_t stream);
 
 /* Backward of ali_assemble_planes for one embedding table (mnist.py:17-18,46-55 and copies: Embedding -> 16x16 ->
  * nearest Upsample -> Tanh):  out[n][cell] = sum over samples b with idx[b*idx_ld + idx_col] == n and over the pixels
@@ -346,7 +347,10 @@ int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* 
  * Fixed summation order (no atomics).  out is [n_rows][256]. */
 int ali_plane_table_grad(const float* g, int32_t g_ld, int32_t g_ch, const float* x, int32_t x_ld, int32_t x_ch,
                          const int32_t* idx, int32_t idx_ld, int32_t idx_col, int32_t B, int32_t H, int32_t W,
-                         int32_t n_rows, float* out, ali_stream_t stream);
+                         int32_t n_rows, float* out,
+                         const float* table /* optional [n_rows][256]: take the plane value tanh(table[n][cell]) from
+                         the table instead of x (x may then be NULL): the stored planes may carry a Dropout2d mask */,
+                         ali_stream_t stream);
 
 /* Gather half of a strided transposed convolution in scatter form (ConvTranspose2d forward with one or two output
  * channels -- audio_mnist.py:281, whalecalls.py / esrf_acoustic.py Generator tails -- and the few input planes of a
