@@ -107,6 +107,8 @@ SIGNATURES = {
     "ali_tconv1_wgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int64, c_int64]
                          + [c_int32] * 7 + [c_void_p, c_size_t, c_void_p]),
     "ali_last_error": (c_char_p, []),
+    "ali_head_fwd": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ali_head_wgrad": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "ali_copy_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "ali_version": (c_int32, []),
     "ali_reload_tuning": (None, []),

@@ -239,6 +239,14 @@ def _is_tconv1(st: Stage, cin_stride: int) -> bool:
             and m.kernel_size[0] <= 5 and cin_stride in (32, 64, 128, 256) and st.act in (ACT_NONE, ACT_LEAKY, ACT_TANH))
 
 
+def _is_head(st: Stage, in_shape) -> bool:
+    """Conv2d(C, 1, 1) on a 1x1 map without activation (the Discriminator's last layer, mnist.py:127): a GEMV"""
+    m = st.mod
+    return (st.kind == "conv" and m.out_channels == 1 and tuple(m.kernel_size) == (1, 1) and m.stride[0] == 1
+            and m.padding[0] == 0 and in_shape[1] == 1 and in_shape[2] == 1 and in_shape[3] % 4 == 0
+            and st.act == ACT_NONE)
+
+
 def _scatter_fwd(st: Stage, cin_stride: int) -> bool:
     """ConvTranspose2d with one or two output channels that the direct kernels do not cover (stride 2 Generator tails of
     the spectrogram models): per-input-pixel tap contributions by a 1x1 GEMM with N = Cout*R*S columns, then
@@ -435,7 +443,9 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             ep.in_ch_live = c_log          # channel padding of a first layer: kernels that can skip it do
         # (the register-blocked tconv1_fwd beats the scatter form on the MNIST tail by 17 us per launch; the scatter
         # form serves the stride-2 / two-channel tails of the spectrogram Generators)
-        if _scatter_fwd(st, Cp) and folded is None and not _is_tconv1(st, Cp):
+        if _is_head(st, (B, H, W, Cp)) and folded is None and bn_fwd is None and not out_ld:
+            ops.head_fwd(t.reshape(B, Cp), plan.packed(st, "fwd", Cp).reshape(-1), plan.packed_bias(st), y.reshape(B))
+        elif _scatter_fwd(st, Cp) and folded is None and not _is_tconv1(st, Cp):
             m = st.mod
             R, S = m.kernel_size
             Co = m.out_channels
@@ -525,7 +535,9 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                 else:
                     grads[id(m.bias)] = ops.colsum(rows_out, K, K, g_pre, out=grad_dst.get(id(m.bias)))
             dw = grad_dst[id(m.weight)] if id(m.weight) in grad_dst else torch.empty_like(m.weight)
-            if st.kind == "conv" and i == 0 and _first_conv_direct(st, c_in_log) and not gemm_first:
+            if _is_head(st, sv.in_shape) and not ld:
+                ops.head_wgrad(sv.t.reshape(B, Cp)[:, :c_in_log], g_pre.reshape(B), dw.reshape(-1), db=fused_db)
+            elif st.kind == "conv" and i == 0 and _first_conv_direct(st, c_in_log) and not gemm_first:
                 T = m.kernel_size[0] * m.kernel_size[1]
                 # dW[k][c][tap] = sum big=g_pre[..,k] * small=t[..,c], all input channels in one launch
                 ops.tconv1_wgrad(g_pre, sv.t, Cp, c_in_log, dw, c_in_log * T, 1, T, B, P, Q, K,

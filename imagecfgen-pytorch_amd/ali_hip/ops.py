@@ -542,6 +542,22 @@ def pack_weights(src, dst, N, T, C, Cpad, s_n, s_tap, s_c):
     return dst
 
 
+def head_fwd(x2d, w, bias, y):
+    """y[b] = bias + x2d[b, :] @ w  (the Discriminator's Conv2d(C, 1, 1) head; include/ali_hip.h: ali_head_fwd)"""
+    B, C = x2d.shape
+    _lib.check(_lib.load().ali_head_fwd(_ptr(x2d), x2d.stride(0), _chk(w, "w"), _opt(bias, "bias"), _chk(y, "y"), B, C,
+                                        _stream()), "ali_head_fwd")
+    return y
+
+
+def head_wgrad(x2d, g, dw, db=None):
+    """dw[c] = sum_b g[b] * x2d[b, c], db = sum_b g[b]  (include/ali_hip.h: ali_head_wgrad)"""
+    B, C = x2d.shape
+    _lib.check(_lib.load().ali_head_wgrad(_ptr(x2d), x2d.stride(0), _chk(g, "g"), _chk(dw, "dw"), _opt(db, "db"), B, C,
+                                          _stream()), "ali_head_wgrad")
+    return dw
+
+
 def copy_multi(pairs):
     """[(dst, src), ...]: dst.copy_(src) for all pairs -- same-dtype contiguous CUDA pairs share one launch
     (include/ali_hip.h: ali_copy_multi), anything else falls back to Tensor.copy_."""

@@ -864,6 +864,48 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
   }
 }
 
+// ---- the one-output head of the Discriminator (Conv2d(1024, 1, 1) on a 1x1 map, mnist.py:127): a GEMV and its
+// weight gradient.  As GEMMs they use 1/64 of a tile and need four launches (GEMM + slab fold + two column-sum stages).
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per row
+  if (row >= B) return;
+  const float* xr = x + (long long)row * ld;
+  float acc = 0.f;
+  for (int c = lane * 4; c + 3 < C; c += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + c), b = *reinterpret_cast<const f32x4*>(w + c);
+    acc += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) y[row] = acc + (bias ? bias[0] : 0.f);
+}
+
+// dw[c] = sum_b g[b] * x[b][c], db = sum_b g[b]: 64 columns x 4 row lanes per block, the row lanes meet in LDS (fixed order)
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, int ld, const float* __restrict__ g,
+                                                         float* __restrict__ dw, float* __restrict__ db, int B, int C) {
+  __shared__ float red[4][65];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a0 = 0.f, a1 = 0.f, s0 = 0.f;
+  if (c < C) {
+    int b = rl;
+    for (; b + 4 < B; b += 8) {
+      a0 += g[b] * x[(long long)b * ld + c];
+      a1 += g[b + 4] * x[(long long)(b + 4) * ld + c];
+    }
+    for (; b < B; b += 4) a0 += g[b] * x[(long long)b * ld + c];
+  }
+  if (blockIdx.x == 0 && cl == 0 && db)
+    for (int b = rl; b < B; b += 4) s0 += g[b];
+  red[rl][cl] = a0 + a1;
+  if (cl == 0) red[rl][64] = s0;
+  __syncthreads();
+  if (rl == 0) {
+    if (c < C) dw[c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    if (blockIdx.x == 0 && cl == 0 && db) db[0] = ((red[0][64] + red[1][64]) + red[2][64]) + red[3][64];
+  }
+}
+
 // ---- several small device-to-device copies in one launch (the step's inputs into the captured graph's buffers) --------
 constexpr int kCopyJobs = 8;
 struct CopyJobs { int n; const unsigned* src[kCopyJobs]; unsigned* dst[kCopyJobs]; long long words[kCopyJobs]; int blk0[kCopyJobs + 1]; };
@@ -939,6 +981,20 @@ extern "C" int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, f
   jobs.n = n_jobs;
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)blk), dim3(kEwBlock), 0, ST(stream), jobs);
   return check_launch("pack_weights_multi_kernel");
+}
+
+extern "C" int ali_head_fwd(const float* x, int32_t ld, const float* w, const float* bias, float* y, int32_t B, int32_t C,
+                            ali_stream_t stream) {
+  if (!x || !w || !y || B <= 0 || C <= 0 || (C % 4) || ld < C || (ld % 4)) { set_error("ali_head_fwd: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, ST(stream), x, ld, w, bias, y, B, C);
+  return check_launch("head_fwd_kernel");
+}
+
+extern "C" int ali_head_wgrad(const float* x, int32_t ld, const float* g, float* dw, float* db, int32_t B, int32_t C,
+                              ali_stream_t stream) {
+  if (!x || !g || !dw || B <= 0 || C <= 0 || ld < C) { set_error("ali_head_wgrad: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3((C + 63) / 64), dim3(256), 0, ST(stream), x, ld, g, dw, db, B, C);
+  return check_launch("head_wgrad_kernel");
 }
 
 extern "C" int ali_copy_multi(int32_t n, const void* const* src, void* const* dst, const int64_t* bytes, ali_stream_t stream) {

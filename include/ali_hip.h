@@ -372,6 +372,13 @@ int ali_spect_post(const float* y, int32_t B, int32_t T, int32_t F, const float*
                    float* out, ali_stream_t stream);
 
 const char* ali_last_error(void);
+/* The Discriminator's one-output head, Conv2d(C, 1, 1) on a 1x1 map (mnist.py:127), as a GEMV:
+ *   ali_head_fwd  : y[b] = bias[0] + sum_c x[b][c] * w[c]            (x rows ld floats apart, C % 4 == 0)
+ *   ali_head_wgrad: dw[c] = sum_b g[b] * x[b][c],  db[0] = sum_b g[b] (db optional)                          */
+int ali_head_fwd(const float* x, int32_t ld, const float* w, const float* bias, float* y, int32_t B, int32_t C,
+                 ali_stream_t stream);
+int ali_head_wgrad(const float* x, int32_t ld, const float* g, float* dw, float* db, int32_t B, int32_t C,
+                   ali_stream_t stream);
 /* n device-to-device copies (dst[i] <- src[i], bytes[i] each; pointers and sizes multiples of 4) in one launch per 8:
  * the per-step refresh of the input buffers a captured HIP graph reads. */
 int ali_copy_multi(int32_t n, const void* const* src, void* const* dst, const int64_t* bytes, ali_stream_t stream);

@@ -423,6 +423,24 @@ def test_deferred_weight_gradients_match_their_own_launches():
         assert torch.equal(dw, dwr) and torch.equal(db, dbr)
 
 
+@pytest.mark.parametrize("B,C,ld", [(512, 1024, 1024), (70, 36, 40), (1030, 512, 512)])
+def test_discriminator_head_gemv(B, C, ld):
+    """ali_head_fwd / ali_head_wgrad: Conv2d(C, 1, 1) on a 1x1 map (mnist.py:127) as a GEMV and its weight / bias gradient."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, ld, generator=g)
+    w = torch.randn(C, generator=g) / C ** 0.5
+    b = torch.randn(1, generator=g)
+    gy = torch.randn(B, generator=g)
+    xd = x.cuda()
+    y = ops.head_fwd(xd[:, :C], w.cuda(), b.cuda(), torch.empty(B, device="cuda"))
+    close(y, (x[:, :C].double() @ w.double() + b.double()).float(), what="head fwd")
+    dw, db = torch.empty(C, device="cuda"), torch.empty(1, device="cuda")
+    ops.head_wgrad(xd[:, :C], gy.cuda(), dw, db)
+    close(dw, (gy.double() @ x[:, :C].double()).float(), what="head dw")
+    close(db, gy.double().sum().float().reshape(1), rtol=1e-5, what="head db")
+
+
 def test_copy_multi_and_mask_peek():
     ops = _ops()
     from ali_hip import dropout
