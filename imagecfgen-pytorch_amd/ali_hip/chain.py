@@ -152,22 +152,25 @@ class ChainPlan:
                 out = buf(R * S * len(which[1]), 1, K)
                 out[:, 0, :].copy_(sel.permute(2, 3, 0, 1).reshape(R * S * len(which[1]), K))
                 return out
+            if w.dim() == 4:
+                src = _storage_view(w)     # (weights may live in the forward pack's order already: FlatGroup.layouts)
+                s0, s1, _, s3 = w.stride()
             if st.kind == "conv":
                 K, C, R, S = w.shape
                 T = R * S
                 if which == "fwd":      # [K][T][Cpad]
-                    return ops.pack_weights(w.detach(), buf(K, T, cin_stride), K, T, C, cin_stride, C * T, 1, T)
+                    return ops.pack_weights(src, buf(K, T, cin_stride), K, T, C, cin_stride, s0, s3, s1)
                 out = buf(cin_stride, T, K, zero=True)             # [Cpad][T][K]; rows >= C stay zero
-                ops.pack_weights(w.detach(), out, C, T, K, K, T, 1, C * T)
+                ops.pack_weights(src, out, C, T, K, K, s1, s3, s0)
                 return out
             if st.kind == "convT":
                 Ci, Co, R, S = w.shape
                 T = R * S
                 if which == "fwd":      # convT forward == data-gradient GEMM: [Co][T][Ci_pad]
-                    return ops.pack_weights(w.detach(), buf(Co, T, cin_stride), Co, T, Ci, cin_stride, T, 1, Co * T)
+                    return ops.pack_weights(src, buf(Co, T, cin_stride), Co, T, Ci, cin_stride, s1, s3, s0)
                 # convT dgrad == conv forward GEMM: [Ci_pad][T][Co]; rows >= Ci stay zero
                 out = buf(cin_stride, T, Co, zero=True)
-                ops.pack_weights(w.detach(), out, Ci, T, Co, Co, Co * T, 1, T)
+                ops.pack_weights(src, out, Ci, T, Co, Co, s0, s3, s1)
                 return out
             # linear (+Unflatten(C,h,w)): 1x1 conv whose output channel n' = t*C + co is NHWC [B,h,w,C]
             O, I = w.shape
@@ -180,6 +183,11 @@ class ChainPlan:
             ops.pack_weights(fwd, out, I, 1, O, O, 1, 0, cin_stride)
             return out
 
+        if which == "fwd" and not ops._PRECISION["f16"] and w.dim() == 4 and tuple(w.stride()) == _fwd_pack_strides(st) \
+                and cin_stride == (w.shape[1] if st.kind == "conv" else w.shape[0]):
+            # the master weights ARE the forward pack (FlatGroup.layouts): no copy to refresh
+            n_out = w.shape[0] if st.kind == "conv" else w.shape[1]
+            return _storage_view(w).view(n_out, w.shape[2] * w.shape[3], cin_stride)
         val = self.cache.get((st.index, which, cin_stride), w, build)
         if ops._PRECISION["f16"] and which in ("fwd", "dgrad"):
             with torch.no_grad():
@@ -328,6 +336,40 @@ def slice_saved(saved, group: int, groups: int):
         s2.geom = ops.geom(B, g.H, g.W, g.C, g.P, g.Q, g.K, g.R, g.S, g.stride, g.pad)
         out.append(s2)
     return out
+
+
+def _fwd_pack_strides(st: Stage):
+    """Strides that make a 4-d conv weight's storage order the forward GEMM's pack ([N][R*S][Cin]: for a Conv2d weight
+    torch's channels_last), or None when the stage's forward pack is not a permutation of the weight (padded input
+    channels, one-channel / scatter tails, Linear)."""
+    w = st.mod.weight
+    if w.dim() != 4 or st.index == 0:      # (first layers: padded planes, direct / scatter kernels with their own packs)
+        return None
+    if st.kind == "conv":
+        K, C, R, S = w.shape
+        return (R * S * C, 1, S * C, C) if C % 4 == 0 else None
+    if st.kind == "convT":
+        Ci, Co, R, S = w.shape
+        if Ci % 32 != 0 or _is_tconv1(st, Ci) or _scatter_fwd(st, Ci):
+            return None
+        return (1, R * S * Ci, S * Ci, Ci)
+    return None
+
+
+def pack_layouts(plans):
+    """{id(weight): strides} for FlatGroup(layouts=...): every conv weight whose forward pack is a permutation of it"""
+    out = {}
+    for pl in plans:
+        for st in pl.stages:
+            strides = _fwd_pack_strides(st)
+            if strides is not None:
+                out[id(st.mod.weight)] = strides
+    return out
+
+
+def _storage_view(w):
+    """the dense storage range of a (possibly permuted) parameter as a contiguous 1-d tensor"""
+    return torch.as_strided(w.detach(), (w.numel(),), (1,))
 
 
 def join_ok(plan: ChainPlan) -> bool:
@@ -544,7 +586,8 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                                  m.kernel_size[0], m.kernel_size[1], m.padding[0])
             elif st.kind == "conv":
                 T = m.kernel_size[0] * m.kernel_size[1]
-                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, c_in_log * T, T, 1, db=fused_db, dy_ld=ld, defer=fold)
+                ops.conv_bwd_weight(g, sv.t, g_pre, dw, c_in_log, K, dw.stride(0), dw.stride(1), dw.stride(3), db=fused_db,
+                                    dy_ld=ld, defer=fold)
             elif _is_tconv1(st, Cp):
                 T = m.kernel_size[0] * m.kernel_size[1]
                 ops.tconv1_wgrad(sv.t, g_pre, 1, 1, dw, T, 1, 0, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1],
@@ -552,7 +595,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             elif st.kind == "convT":
                 T = m.kernel_size[0] * m.kernel_size[1]
                 # gathered operand = convT output-grad (channels K), dense = convT input (channels Cp)
-                ops.conv_bwd_weight(g, g_pre, sv.t, dw, K, c_in_log, K * T, T, 1, defer=fold)
+                ops.conv_bwd_weight(g, g_pre, sv.t, dw, K, c_in_log, dw.stride(0), dw.stride(1), dw.stride(3), defer=fold)
             else:
                 O, I = m.weight.shape
                 Cc, hh, ww = st.unflat if st.unflat else (O, 1, 1)

@@ -409,7 +409,7 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
 
     def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _ptr(dy) if dy_ld else _chk(dy, "dy"),
-                                           _chk(dst, "dst"), cg_log, cd_log,
+                                           _ptr(dst), cg_log, cd_log,        # (dst: any strides, see s_dc / s_gc / s_tap)
                                            s_dc, s_gc, s_tap, _opt(db, "db"),
                                            None if tab is None else c_void_p(tab.data_ptr()), f16,
                                            None if x16 is None else c_void_p(x16.data_ptr()),

@@ -31,9 +31,15 @@ from .chain import chain_backward, chain_forward, get_plan, slice_saved
 
 
 class FlatGroup:
-    """Parameters re-pointed into one flat buffer + flat grad / exp_avg / exp_avg_sq buffers."""
+    """Parameters re-pointed into one flat buffer + flat grad / exp_avg / exp_avg_sq buffers.
 
-    def __init__(self, params, lr, betas, eps):
+    ``layouts`` (optional, {id(param): strides}): the element order a parameter takes inside its segment of the flat
+    buffers -- a dense permutation given as the strides of the (logically unchanged) parameter tensor.  The stepper
+    asks for the forward GEMM's weight layout (`[K][R*S][C]`: torch's channels_last for a Conv2d weight), so that the
+    optimiser step itself leaves the weights in kernel layout and half of the re-pack disappears; Adam is elementwise
+    and does not care.  Gradients, exp_avg and exp_avg_sq use the same order (``*_views``)."""
+
+    def __init__(self, params, lr, betas, eps, layouts=None):
         self.params = list(params)
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
@@ -42,20 +48,44 @@ class FlatGroup:
         self.grad = torch.zeros(n, device=dev)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
-        self.grad_views = {}
+        self.grad_views, self.m_views, self.v_views = {}, [], []
+        layouts = layouts or {}
         off = 0
         with torch.no_grad():
             for p in self.params:
                 k = p.numel()
-                self.flat[off:off + k].copy_(p.detach().reshape(-1))
-                p.data = self.flat[off:off + k].view(p.shape)
-                gv = self.grad[off:off + k].view(p.shape)
+                st = layouts.get(id(p))
+
+                def view(buf):
+                    seg = buf[off:off + k]
+                    return seg.view(p.shape) if st is None else torch.as_strided(seg, p.shape, st)
+                w = view(self.flat)
+                w.copy_(p.detach())
+                p.data = w
+                gv = view(self.grad)
                 p.grad = gv
                 self.grad_views[id(p)] = gv
+                self.m_views.append(view(self.m))
+                self.v_views.append(view(self.v))
                 off += k
         self.lr, self.betas, self.eps = lr, betas, eps
         self.steps = 0
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)
+
+    @staticmethod
+    def logical(views):
+        """the buffer behind ``views`` as one flat tensor in the parameters' own (row-major) element order"""
+        return torch.cat([v.reshape(-1) for v in views])
+
+    def grad_logical(self):
+        """the flat gradient in the parameters' own element order (tests, diagnostics)"""
+        return self.logical(list(self.grad_views.values()))
+
+    def load_logical(self, views, flat):
+        off = 0
+        for v in views:
+            v.copy_(flat[off:off + v.numel()].view(v.shape))
+            off += v.numel()
 
     def adam(self, grad_scale=1.0):
         self.steps += 1
@@ -73,8 +103,8 @@ class FlatGroup:
     def state_dict(self):
         # the device-side count is the authoritative one: HIP-graph replays do not run the host-side increment
         self.steps = int(self.step_t.item())
-        return {"step": self.steps, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr, "betas": self.betas,
-                "eps": self.eps}
+        return {"step": self.steps, "exp_avg": self.logical(self.m_views), "exp_avg_sq": self.logical(self.v_views),
+                "lr": self.lr, "betas": self.betas, "eps": self.eps}
 
 
 class MnistFamily:
@@ -164,8 +194,11 @@ class AliStepper:
         self.family = family or family_of(E, G, D)
         self.pE, self.pG = get_plan(E.layers), get_plan(G.layers)
         self.pDx, self.pDz, self.pDxz = get_plan(D.dx), get_plan(D.dz), get_plan(D.dxz)
-        self.opt_eg = FlatGroup(list(E.parameters()) + list(G.parameters()), lr, betas, eps)
-        self.opt_d = FlatGroup(list(D.parameters()), lr, betas, eps)
+        # fp32: master weights live in the forward GEMM's layout (FlatGroup.layouts; chain.packed then aliases them).
+        # The fp16 path keeps the re-pack: that launch also writes the fp16 twins the kernels read.
+        lay = _chain.pack_layouts([self.pE, self.pG, self.pDx, self.pDz, self.pDxz]) if precision == "f32" else None
+        self.opt_eg = FlatGroup(list(E.parameters()) + list(G.parameters()), lr, betas, eps, layouts=lay)
+        self.opt_d = FlatGroup(list(D.parameters()), lr, betas, eps, layouts=lay)
         for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
             pl.cache.store.clear()
             pl.cache.static = True
@@ -522,19 +555,16 @@ class AliStepper:
             if opt is None:
                 continue
             src_params = [p for m in mods for p in m.parameters()]
-            off = 0
             step = 0
-            for p_src, p_dst in zip(src_params, group.params):
+            for p_src, mv, vv in zip(src_params, group.m_views, group.v_views):
                 st = opt.state.get(p_src, {})
-                n = p_dst.numel()
                 if st:
-                    group.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
-                    group.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    mv.copy_(st["exp_avg"])
+                    vv.copy_(st["exp_avg_sq"])
                     step = int(st["step"])
                 else:
-                    group.m[off:off + n].zero_()
-                    group.v[off:off + n].zero_()
-                off += n
+                    mv.zero_()
+                    vv.zero_()
             group.steps = step
             group.step_t.fill_(step)
         for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
@@ -547,7 +577,8 @@ class AliStepper:
         iteration counter that keys the dropout masks.  Tensors are cloned to the CPU."""
         def opt(g):
             # the device-side count is the authoritative one: graph replays do not run the host-side increment
-            return {"step": int(g.step_t.item()), "exp_avg": g.m.cpu().clone(), "exp_avg_sq": g.v.cpu().clone()}
+            return {"step": int(g.step_t.item()), "exp_avg": g.logical(g.m_views).cpu(),
+                    "exp_avg_sq": g.logical(g.v_views).cpu()}
         sd = {f"{n}_state_dict": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
               for n, m in (("E", self.E), ("G", self.G), ("D", self.D))}
         sd.update(optimizer_E=opt(self.opt_eg), optimizer_D=opt(self.opt_d), iteration=int(self.iter_t.item()),
@@ -568,7 +599,8 @@ class AliStepper:
                     g.m.zero_(), g.v.zero_()
                     g.steps = 0
                 else:
-                    g.m.copy_(o["exp_avg"]), g.v.copy_(o["exp_avg_sq"])
+                    g.load_logical(g.m_views, o["exp_avg"].to(g.m.device))
+                    g.load_logical(g.v_views, o["exp_avg_sq"].to(g.v.device))
                     g.steps = int(o["step"])
                 g.step_t.fill_(g.steps)
             self.iter_t.fill_(int(sd.get("iteration", 0)))

@@ -880,29 +880,41 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
   if (lane == 0) y[row] = acc + (bias ? bias[0] : 0.f);
 }
 
-// dw[c] = sum_b g[b] * x[b][c], db = sum_b g[b]: 64 columns x 4 row lanes per block, the row lanes meet in LDS (fixed order)
+// dw[c] = sum_b g[b] * x[b][c], db = sum_b g[b]: 32 columns x 8 row lanes per block, eight independent loads in flight per
+// thread (the loop is latency bound: 2 MB of x behind a handful of blocks), the row lanes meet in LDS (fixed order)
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, int ld, const float* __restrict__ g,
                                                          float* __restrict__ dw, float* __restrict__ db, int B, int C) {
-  __shared__ float red[4][65];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float a0 = 0.f, a1 = 0.f, s0 = 0.f;
-  if (c < C) {
-    int b = rl;
-    for (; b + 4 < B; b += 8) {
-      a0 += g[b] * x[(long long)b * ld + c];
-      a1 += g[b + 4] * x[(long long)(b + 4) * ld + c];
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  float s0 = 0.f;
+  const bool sum_g = blockIdx.x == 0 && cl == 0 && db != nullptr;
+  if (c < C || sum_g) {
+    const int cc = c < C ? c : 0;
+    for (int b0 = rl; b0 < B; b0 += 64) {
+      float gv[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 8 * u;
+        gv[u] = b < B ? g[b] : 0.f;
+        xv[u] = b < B ? x[(long long)b * ld + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc[u] += gv[u] * xv[u]; s0 += gv[u]; }
     }
-    for (; b < B; b += 4) a0 += g[b] * x[(long long)b * ld + c];
   }
-  if (blockIdx.x == 0 && cl == 0 && db)
-    for (int b = rl; b < B; b += 4) s0 += g[b];
-  red[rl][cl] = a0 + a1;
-  if (cl == 0) red[rl][64] = s0;
+  red[rl][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  if (cl == 0) red[rl][32] = s0;
   __syncthreads();
   if (rl == 0) {
-    if (c < C) dw[c] = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
-    if (blockIdx.x == 0 && cl == 0 && db) db[0] = ((red[0][64] + red[1][64]) + red[2][64]) + red[3][64];
+    float v = red[0][cl], sg = red[0][32];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { v += red[r][cl]; sg += red[r][32]; }
+    if (c < C) dw[c] = v;
+    if (sum_g) db[0] = sg;
   }
 }
 
@@ -993,7 +1005,7 @@ extern "C" int ali_head_fwd(const float* x, int32_t ld, const float* w, const fl
 extern "C" int ali_head_wgrad(const float* x, int32_t ld, const float* g, float* dw, float* db, int32_t B, int32_t C,
                               ali_stream_t stream) {
   if (!x || !g || !dw || B <= 0 || C <= 0 || ld < C) { set_error("ali_head_wgrad: bad argument"); return ALI_ERR_BAD_ARG; }
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3((C + 63) / 64), dim3(256), 0, ST(stream), x, ld, g, dw, db, B, C);
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3((C + 31) / 32), dim3(256), 0, ST(stream), x, ld, g, dw, db, B, C);
   return check_launch("head_wgrad_kernel");
 }
 

@@ -224,7 +224,7 @@ def test_fp16_mfma_stepper_iteration_vs_fp32_oracle(family, d, B):
         loss scale out, every GEMM on the right operands.  The Adam step: bounded by lr per element, close on average."""
         g_o = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).double()
                          for m in mods_o for p in m.parameters()])
-        g_p = group.grad.double().cpu() / stepper.loss_scale
+        g_p = group.grad_logical().double().cpu() / stepper.loss_scale
         rel = ((g_p - g_o).norm() / g_o.norm()).item()
         assert rel <= 6e-2, (what, rel)
         wp = torch.cat([p.detach().reshape(-1).double().cpu() for m in mods_p for p in m.parameters()])
@@ -238,7 +238,7 @@ def test_fp16_mfma_stepper_iteration_vs_fp32_oracle(family, d, B):
         cx = stepper._begin(images.cuda(), to_dev(c), z.cuda())
         w0 = weights((Eo, Go))
         stepper._phase_eg(cx)
-    g_eg_hip = stepper.opt_eg.grad.double().cpu() / stepper.loss_scale
+    g_eg_hip = stepper.opt_eg.grad_logical().double().cpu() / stepper.loss_scale
     loss_eg_hip = cx["out"]["loss_eg"].item()
     oe.zero_grad()
     l_eg = (bce(Do(images, Eo(images, c), c), fake) + bce(Do(Go(z, c), z, c), valid)) / 2
