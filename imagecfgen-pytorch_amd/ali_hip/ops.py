@@ -364,6 +364,10 @@ class FoldQueue:
         pass will combine decides how far each is split (a function of the pass alone -- not of what ran before)."""
         self.n_jobs = max(1, sum(wgrad_deferrable(g) for g in geoms))
 
+    def abandon(self):
+        """forget recorded work without launching it (an iteration that raised half-way)"""
+        self.jobs, self.launches, self.keep, self.flops, self.off = [], [], [], 0.0, 0
+
     def split_target(self):
         """blocks a deferred GEMM should split into: about 2048 in the whole combined launch"""
         return max(256, min(1024, 2048 // self.n_jobs))

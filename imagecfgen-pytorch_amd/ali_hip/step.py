@@ -364,6 +364,8 @@ class AliStepper:
     def _begin(self, images, c, z, do_eg=True):
         B = images.shape[0]
         self.iter_t += 1
+        if self._fold is not None:
+            self._fold.abandon()       # (nothing is pending after a completed iteration)
         _dropout.begin_iteration(self.iter_t, owner=self, tag=(B, bool(do_eg)))
         _chain.defer_batch_counts()
         idx, cont, onehots = self.family.conditioning(c)
