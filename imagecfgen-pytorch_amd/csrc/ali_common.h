@@ -25,6 +25,7 @@ struct Tuning {
   int bm, bn, splitk;                       // ALI_BM / ALI_BN / ALI_SPLITK: force the gconv tile / split
   long long wgrad_small;                    // ALI_WGRAD_SMALL
   int wgrad_blocks, wgrad_scap;             // ALI_WGRAD_BLOCKS / ALI_WGRAD_SCAP
+  int no_first_wgrad;                       // ALI_NO_FIRST_WGRAD=1: the first conv's weight gradient stays a GEMM (A/B)
   int no_order;                             // ALI_NO_ORDER=1: ignore AliEpilogue.tile_order (A/B measurements)
 };
 inline Tuning read_tuning() {
@@ -35,6 +36,7 @@ inline Tuning read_tuning() {
     v.wgrad_small = getenv("ALI_WGRAD_SMALL") ? num("ALI_WGRAD_SMALL") : -1;
     v.wgrad_blocks = (int)num("ALI_WGRAD_BLOCKS"); v.wgrad_scap = (int)num("ALI_WGRAD_SCAP");
     v.no_order = (int)num("ALI_NO_ORDER");
+    v.no_first_wgrad = (int)num("ALI_NO_FIRST_WGRAD");
     return v;
   }
 }

@@ -709,6 +709,117 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_multi_kernel(const WJobs jo
   wgrad_fast_body<BM, BN, WAVES_M, WAVES_N, TAB, F16>(J.d, J.xb, J.yb, bx, t2 % J.gy, t2 / J.gy);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the Discriminator's first conv (mnist.py:118: 5 planes padded to 8 -> 32 channels, 5x5, stride 1) as
+// a per-image LDS-resident kernel, the counterpart of conv_first_kernel (gconv.hip).  As a GEMM it is 200 x 32 over
+// 295 k pixels with 75 of the 200 rows channel padding, two 128-row tiles, one block per CU: 69 us.  Here a block keeps
+// the image's live planes in LDS (pitch CL, odd), streams the 32-channel output gradient through LDS FW_GR rows at a
+// time (double buffered, fetched one chunk ahead), and wave w accumulates dW[k][n], n = 32 w + lane (n = tap * CL + c,
+// 125 of 128 live), over all pixels of all its images in ONE MFMA accumulator: A = g^T (k x pixel), B = shifted image
+// reads (pixel x (tap, c)), both one ds_read_b32 per MFMA.  Every block leaves a slab [tap * CL + c][k] (+ its
+// bias-gradient row) for the usual slab fold.
+constexpr int FW_GR = 4;
+template <int CL, int RS>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const WDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float fw_smem[];
+  float* img = fw_smem;                                  // [H*W][CL]
+  float* gch = fw_smem + d.H * d.W * CL;                 // [2][FW_GR*Q][33]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = wave * 32 + (lane & 31), kk = lane >> 5;
+  constexpr int KL = RS * RS * CL;
+  const bool live = n < KL;
+  const int tap = live ? n / CL : 0, c = live ? n - tap * CL : 0;
+  const int boff = ((tap / RS) * d.W + (tap % RS)) * CL + c;
+  f32x16 acc, acc1;                                      // two accumulators: two independent MFMA chains
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+  const int HW = d.H * d.W;
+  const int nchunk = (d.P + FW_GR - 1) / FW_GR;
+  const int gch_sz = FW_GR * d.Q * 33;
+  constexpr int PF = (FW_GR * 32 * 8 + 255) / 256;      // float4 per thread per chunk (Q <= 32)
+  f32x4 pf[PF];
+  // chunk (b, ci): FW_GR rows of the output gradient of image b; fetched into registers one chunk ahead of its use
+  auto fetch = [&](int b, int ci) {
+    const int p0 = ci * FW_GR;
+    const int npx = min(FW_GR, d.P - p0) * d.Q;
+    const float* gsrc = d.dy + ((long long)(b * d.P + p0) * d.Q) * 32;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = t + u * 256;
+      pf[u] = i < npx * 8 ? *reinterpret_cast<const f32x4*>(gsrc + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int buf = 0;
+  if ((int)blockIdx.x < d.B) fetch(blockIdx.x, 0);
+  for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+    __syncthreads();                                     // the previous image's last chunk has been consumed
+    const float* src = d.x + (long long)b * HW * 8;
+    for (int i = t; i < HW * 2; i += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
+      float* dst = img + (i >> 1) * CL + (i & 1) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((i & 1) * 4 + e < CL) dst[e] = v[e];
+    }
+    for (int ci = 0; ci < nchunk; ++ci) {
+      const int p0 = ci * FW_GR;
+      const int rows = min(FW_GR, d.P - p0), npx = rows * d.Q;
+      float* gc = gch + buf * gch_sz;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {                     // (i & 7 == t & 7: a thread always stages the same 4 channels)
+        const int i = t + u * 256;
+        if (i < npx * 8) {
+          float* dst = gc + (i >> 3) * 33 + (i & 7) * 4;
+          dst[0] = pf[u][0]; dst[1] = pf[u][1]; dst[2] = pf[u][2]; dst[3] = pf[u][3];
+          dbacc += pf[u];
+        }
+      }
+      __syncthreads();                                   // chunk (and, for ci == 0, the image) visible; the other buffer is free
+      if (ci + 1 < nchunk) fetch(b, ci + 1);             // the next chunk travels while this one is multiplied
+      else if (b + (int)gridDim.x < d.B) fetch(b + gridDim.x, 0);
+      // pixels (row pr, column q = kk, kk + 2, ...) of the chunk, four MFMA operand pairs requested at a time (the loop is
+      // one dependent MFMA chain: without the batching every step would also wait for its two LDS reads)
+      for (int pr = 0; pr < rows; ++pr) {
+        const float* arow = gc + (pr * d.Q) * 33 + (lane & 31);
+        const float* irow = img + ((p0 + pr) * d.W) * CL + boff;
+        for (int q0 = kk; q0 < d.Q; q0 += 8) {
+          float av[4], bw[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = q0 + 2 * u;
+            const bool in = q < d.Q;
+            av[u] = in ? arow[q * 33] : 0.f;
+            bw[u] = (in && live) ? irow[q * CL] : 0.f;
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bw[0], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bw[1], acc1, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bw[2], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bw[3], acc1, 0, 0, 0);
+        }
+      }
+      buf ^= 1;
+    }
+  }
+  // slab of this block: [n][k] (+ pad rows never read), then its bias-gradient row
+  float* slab = d.ws + (long long)blockIdx.x * d.slab;
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[n * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk] = acc[r] + acc1[r];
+  }
+  if (d.db) {
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(gch);          // [32 thread groups][8 channel chunks]
+    red[(t >> 3) * 8 + (t & 7)] = dbacc;
+    __syncthreads();
+    if (t < 8) {
+      f32x4 s4 = red[t];
+      for (int q = 1; q < 32; ++q) s4 += red[q * 8 + t];
+      *reinterpret_cast<f32x4*>(d.dbws + (long long)blockIdx.x * 32 + t * 4) = s4;
+    }
+  }
+}
+
 __global__ void wgrad_pixtab_kernel(int npix, int P, int Q, int H, int W, int Cg, int stride, int* __restrict__ out) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= npix) return;
@@ -944,6 +1055,40 @@ extern "C" int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const f
   if (!fast && d.ldd != g->K) { set_error("ali_conv_bwd_weight: dy_ld on a tensor too large for the vector kernels"); return ALI_ERR_BAD_ARG; }
   int bm, bn;
   wgrad_tile(g, fast, mfma_f16 && pixtab, bm, bn);
+  // the Discriminator's first conv (5 live planes in 8, 32 output channels, 5x5 stride 1 on maps up to 32 x 32): per-image
+  // LDS-resident kernel; its per-block slabs take the usual fold (deferred with `fold`, or right here)
+  const bool first_lds = fast && !mfma_f16 && tuning().no_first_wgrad == 0 && g->C == 8 && Cg_log == 5 && g->K == 32 &&
+                         g->stride == 1 && g->pad == 0 && g->R == 5 && g->S == 5 && g->H <= 32 && g->W <= 32 &&
+                         g->B >= 64 && d.ldd == g->K && g->P == g->H - 4 && g->Q == g->W - 4;
+  if (first_lds) {
+    int S = g->B < kNumCU ? g->B : kNumCU;
+    d.Mtot = 25 * 5; d.Cg = 5;
+    d.slab = (long long)d.Mtot * g->K + kSlabPad;
+    if (((size_t)S * d.slab + (size_t)S * g->K) * sizeof(float) > ws_bytes) { set_error("ali_conv_bwd_weight: workspace too small"); return ALI_ERR_WORKSPACE; }
+    d.splitk = S;
+    d.db = db;
+    d.dbws = d.ws + (size_t)S * d.slab;
+    const size_t lds = ((size_t)g->H * g->W * 5 + (size_t)2 * FW_GR * g->Q * 33) * sizeof(float);
+    hipLaunchKernelGGL((conv_first_wgrad_kernel<5, 5>), dim3(S), dim3(256), lds, stream, d);
+    int rc1 = check_launch("conv_first_wgrad_kernel");
+    if (rc1) return rc1;
+    if (fold) {
+      fold->ws = d.ws; fold->dst = dst; fold->dbws = d.dbws; fold->db = d.db;
+      fold->slab = d.slab; fold->s_dc = s_dc; fold->s_gc = s_gc; fold->s_tap = s_tap;
+      fold->S = S; fold->Mtot = d.Mtot; fold->Cg = 5; fold->Cd = g->K; fold->Cg_log = 5; fold->Cd_log = Cd_log;
+      fold->T = 25; fold->reserved = 0;
+      fold->ws_used = (uint64_t)kWsReserved + ((uint64_t)S * d.slab + (uint64_t)S * g->K) * sizeof(float);
+      return ALI_OK;
+    }
+    const int T = 25, G = 1, TD = 32;
+    int SGN = kRedLds / (G * T);
+    if (SGN > kRedGroups) SGN = kRedGroups;
+    if (SGN > S) SGN = S;
+    hipLaunchKernelGGL(wgrad_reduce_tile_kernel<32>, dim3(5, (g->K + TD - 1) / TD), dim3(256), 0, stream, d.ws, S, d.Mtot, 5,
+                       d.Cd, 5, Cd_log, (long long)s_dc, (long long)s_gc, (long long)s_tap, dst, d.dbws, d.db, G, T, SGN,
+                       d.slab);
+    return check_launch("wgrad_reduce_tile_kernel");
+  }
   const int wbk = fast ? WBK2 : WBK;
   const int tiles_m = (d.Mtot + bm - 1) / bm, tiles_n = (g->K + bn - 1) / bn;
   const long long blocks = (long long)tiles_m * tiles_n;
