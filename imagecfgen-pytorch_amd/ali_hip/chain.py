@@ -477,10 +477,11 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
                                                   and (not pixel_major or B % tile_rows == 0))):
                     part = torch.empty(2 * out_shape[3] * slots, dtype=torch.float32, device=cur.device)
                     bn_part = (part, slots)
-                    bn_fwd = (part, groups, early)
+                    bn_fwd = (part, groups, early, slots)
         ep = ops.epilogue(bias=plan.packed_bias(st), act=st.act, slope=st.slope, mask=folded, bn_fwd=bn_fwd)
         if jmask is not None:
             ep.mask, ep.mask_ld = jmask.data_ptr(), jmask.stride(0)
+            ep.refs["mask"] = jmask
         if si == 0 and st.kind == "conv" and c_log < Cp:
             ep.in_ch_live = c_log          # channel padding of a first layer: kernels that can skip it do
         # (the register-blocked tconv1_fwd beats the scatter form on the MNIST tail by 17 us per launch; the scatter
@@ -646,7 +647,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             if slots > 0 and st.kind in ("conv", "convT") and not _is_tconv1(st, Cp):
                 part = torch.empty(2 * Cp * slots, dtype=torch.float32, device=gy.device)
                 bn_red = (part, slots)
-                ep = ops.epilogue(bn_bwd=(part, sv.x_in, sv.bn_stats[0], sv.bn_stats[1], mask_in, mask_pre))
+                ep = ops.epilogue(bn_bwd=(part, sv.x_in, sv.bn_stats[0], sv.bn_stats[1], mask_in, mask_pre, slots))
             else:
                 ep = ops.epilogue()
         if _is_tconv1(st, Cp) and sv.bn is None and sv.mask is None:

@@ -74,10 +74,13 @@ def geom(B, H, W, C, P, Q, K, R, S, stride, pad) -> AliConvGeom:
 
 def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=ACT_NONE, dslope=0.0,
              bn_fwd=None, bn_bwd=None) -> AliEpilogue:
-    """``bn_fwd`` = (part, groups, stat_mask or None): also leave the per-tile (sum, sum of squares) of the output;
-    ``bn_bwd`` = (part, x, mean, invstd, mask_in or None, mask_pre or None): per-tile (sum g~*xhat, sum g~) of a data
-    gradient (include/ali_hip.h, AliEpilogue)."""
+    """``bn_fwd`` = (part, groups, stat_mask or None[, slots]): also leave the per-tile (sum, sum of squares) of the
+    output; ``bn_bwd`` = (part, x, mean, invstd, mask_in or None, mask_pre or None[, slots]): per-tile (sum g~*xhat,
+    sum g~) of a data gradient (include/ali_hip.h, AliEpilogue).  ``slots`` = the slot count ``part`` was sized for
+    (``conv_mtiles``): the launch refuses to run when its own M-tile count differs."""
     ep = AliEpilogue()
+    # (python-side references of the operands behind the raw pointers: keeps them alive, lets a launch hook see them)
+    ep.refs = {"bias": bias, "mask": mask, "dact_y": dact_y, "bn_fwd": bn_fwd, "bn_bwd": bn_bwd}
     ep.bias = _opt(bias, "bias")
     ep.act, ep.slope = act, slope
     ep.mask = _opt(mask, "mask")
@@ -86,12 +89,14 @@ def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=AC
     ep.dact, ep.dslope = dact, dslope
     ep.mfma_f16 = int(_PRECISION["f16"])
     if bn_fwd is not None:
-        part, groups, smask = bn_fwd
+        part, groups, smask = bn_fwd[:3]
+        ep.bn_slots = int(bn_fwd[3]) if len(bn_fwd) > 3 else 0
         ep.bn_part, ep.bn_mode, ep.bn_groups = _chk(part, "bn_part"), 1, groups
         ep.bn_stat_mask = _opt(smask, "bn_stat_mask")
         ep.bn_mask_ld = smask.shape[1] if smask is not None else 0
     elif bn_bwd is not None:
-        part, x, mean, invstd, m_in, m_pre = bn_bwd
+        part, x, mean, invstd, m_in, m_pre = bn_bwd[:6]
+        ep.bn_slots = int(bn_bwd[6]) if len(bn_bwd) > 6 else 0
         ep.bn_part, ep.bn_mode, ep.bn_groups = _chk(part, "bn_part"), 2, 1
         ep.bn_x, ep.bn_mean, ep.bn_invstd = _chk(x, "bn_x"), c_void_p(mean.data_ptr()), c_void_p(invstd.data_ptr())
         ep.bn_mask_in, ep.bn_mask_pre = _opt(m_in, "bn_mask_in"), _opt(m_pre, "bn_mask_pre")
@@ -101,6 +106,39 @@ def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=AC
 
 
 _MTILES = {}
+
+
+def reload_tuning():
+    """Make the library re-read its developer tuning variables (ALI_BM, ALI_BN, ALI_SPLITK, ALI_TILE_M_SCALE, ...:
+    csrc/ali_common.h) and drop every host-side cache that was derived under the old ones (M-tile counts, dispatch-order
+    tables, deferrable flags).  Tests and sweeps only; never while a captured graph that used the old tuning is alive."""
+    _lib.load().ali_reload_tuning()
+    _MTILES.clear()
+    _TILE_ORDER.clear()
+    _DEFERRABLE.clear()
+
+
+class tuning:
+    """``with ops.tuning(ALI_BM=128, ALI_BN=128): ...`` -- set tuning variables for the block, restore them after."""
+
+    def __init__(self, **env):
+        self.env = {k: str(v) for k, v in env.items()}
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+        reload_tuning()
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        reload_tuning()
 
 
 def conv_mtiles(g: AliConvGeom, which: int):
@@ -151,6 +189,30 @@ _PROFILE = None
 def set_profile(p):
     global _PROFILE
     _PROFILE = p
+
+
+_HOOK = None
+
+
+class launch_hook:
+    """``with ops.launch_hook(obj):`` -- tests only.  Every GEMM launch made inside the block is reported to ``obj``
+    right after it has been issued: ``obj.gemm(kind, g, a, w, out, ep, in_ld, out_ld)`` for ``conv_fwd`` ("fwd") /
+    ``conv_bwd_data`` ("bwd_data") and ``obj.wgrad(g, x, dy, dst, cg_log, cd_log, strides, db, dy_ld)`` for
+    ``conv_bwd_weight`` -- the latter returns a callable (or None) that is run once the result is final (at once, or
+    after ``FoldQueue.flush`` for deferred launches).  tests/launch_audit.py re-computes each launch with torch on the
+    CPU from the very operands the kernel read."""
+
+    def __init__(self, obj):
+        self.obj = obj
+
+    def __enter__(self):
+        global _HOOK
+        self.prev, _HOOK = _HOOK, self.obj
+        return self.obj
+
+    def __exit__(self, *exc):
+        global _HOOK
+        _HOOK = self.prev
 
 
 def _geom_cost(g: AliConvGeom):
@@ -286,6 +348,8 @@ def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue, in_ld=0, out_ld=0)
                                     byref(ep),
                                     c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
     _launch("gconv", *_geom_cost(g), go)
+    if _HOOK is not None:
+        _HOOK.gemm("fwd", g, x, w_packed, y, ep, in_ld, out_ld)
     return y
 
 
@@ -301,6 +365,8 @@ def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue, in_ld=0, ou
                                          _view_ptr(dx, out_ld, "dx"), byref(ep),
                                          c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
     _launch("gconv_t", *_geom_cost(g), go)
+    if _HOOK is not None:
+        _HOOK.gemm("bwd_data", g, dy, w_packed, dx, ep, in_ld, out_ld)
     return dx
 
 
@@ -351,6 +417,7 @@ class FoldQueue:
         self.off = 0
         self.flops = 0.0
         self.n_jobs = 1         # deferrable launches of the pass in progress (expect()): what a combined launch will hold
+        self.after_flush = []   # launch_hook callbacks of deferred weight gradients (tests)
 
     def arena(self):
         a = FoldQueue._arena.get(self.device.index)
@@ -367,6 +434,7 @@ class FoldQueue:
     def abandon(self):
         """forget recorded work without launching it (an iteration that raised half-way)"""
         self.jobs, self.launches, self.keep, self.flops, self.off = [], [], [], 0.0, 0
+        self.after_flush = []
 
     def split_target(self):
         """blocks a deferred GEMM should split into: about 2048 in the whole combined launch"""
@@ -389,6 +457,9 @@ class FoldQueue:
                 _lib.check(_lib.load().ali_wgrad_fold_multi(n, arr, _stream()), "ali_wgrad_fold_multi")
             _launch("wgrad_fold", 0.0, (0,) * 10, go)
         self.jobs, self.off = [], 0
+        todo, self.after_flush = self.after_flush, []
+        for fn in todo:
+            fn()
 
 
 def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_tap, db=None, dy_ld=0, defer=None):
@@ -429,9 +500,17 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
             defer.launches.append(lj)
             defer.keep.append((x, dy, dst, db, tab))
             defer.flops += _geom_cost(g)[0]
-    if job is not None and job.S > 0:
+    deferred = job is not None and job.S > 0
+    if deferred:
         defer.jobs.append(job)
         defer.off += (int(job.ws_used) + 255) // 256 * 256
+    if _HOOK is not None:
+        done = _HOOK.wgrad(g, x, dy, dst, cg_log, cd_log, (s_dc, s_gc, s_tap), db, dy_ld)
+        if done is not None:
+            if deferred or (lj is not None and lj.opaque[0] == 1):
+                defer.after_flush.append(done)
+            else:
+                done()
     return dst
 
 

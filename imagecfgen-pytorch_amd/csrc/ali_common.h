@@ -27,6 +27,9 @@ struct Tuning {
   int wgrad_blocks, wgrad_scap;             // ALI_WGRAD_BLOCKS / ALI_WGRAD_SCAP
   int no_first_wgrad;                       // ALI_NO_FIRST_WGRAD=1: the first conv's weight gradient stays a GEMM (A/B)
   int no_order;                             // ALI_NO_ORDER=1: ignore AliEpilogue.tile_order (A/B measurements)
+  int tile_m_scale;                         // ALI_TILE_M_SCALE=n: choose the gconv / wgrad tiles as if the batch were n
+                                            // times larger (tests: a small batch runs the tiles of the bench batch)
+  int wbm, wbn;                             // ALI_WBM / ALI_WBN: force the weight-gradient tile (one of its variants)
 };
 inline Tuning read_tuning() {
   {
@@ -37,6 +40,8 @@ inline Tuning read_tuning() {
     v.wgrad_blocks = (int)num("ALI_WGRAD_BLOCKS"); v.wgrad_scap = (int)num("ALI_WGRAD_SCAP");
     v.no_order = (int)num("ALI_NO_ORDER");
     v.no_first_wgrad = (int)num("ALI_NO_FIRST_WGRAD");
+    v.tile_m_scale = (int)num("ALI_TILE_M_SCALE");
+    v.wbm = (int)num("ALI_WBM"); v.wbn = (int)num("ALI_WBN");
     return v;
   }
 }

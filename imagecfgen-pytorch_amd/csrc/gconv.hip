@@ -957,9 +957,9 @@ static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps) {
     if (d.ph[i].nr * d.ph[i].ns > max_taps) max_taps = d.ph[i].nr * d.ph[i].ns;
     if (d.ph[i].M >= (1 << 24)) { set_error("gconv: more than 2^24 rows in one phase"); return -1; }
   }
-  tc = pick_tile(Mtot, d.Cout, d.f16 && vec && (d.Cin % BK) == 0);
-  if (!vec && tc.bn == 128) tc.bn = 64;
+  tc = pick_tile(Mtot * (tuning().tile_m_scale > 0 ? tuning().tile_m_scale : 1), d.Cout, d.f16 && vec && (d.Cin % BK) == 0);
   if (tuning().bm > 0 && tuning().bn > 0) { tc.bm = tuning().bm; tc.bn = tuning().bn; }
+  if (!vec && tc.bn == 128) tc.bn = 64;
   int tiles = 0;
   for (int i = 0; i < d.nphase; ++i) {
     // small maps with a large batch: order rows (pixel, image) so that every M-tile sees one pixel position
@@ -1015,6 +1015,10 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
       ok = ok && rows_g % tc.bm == 0 && (!d.ph[0].pixmajor || d.B % tc.bm == 0);
     }
     if (!ok) { set_error("gconv: bad fused BatchNorm epilogue (see AliEpilogue / ali_conv_mtiles)"); return ALI_ERR_BAD_ARG; }
+    if (e.bn_slots > 0 && e.bn_slots != tiles) {
+      set_error("gconv: bn_part was sized for %d slots, this launch has %d M-tiles (stale ali_conv_mtiles result?)", e.bn_slots, tiles);
+      return ALI_ERR_BAD_ARG;
+    }
   }
   const int ntile_n = (d.Cout + tc.bn - 1) / tc.bn;
   d.ldi = d.Cin;
@@ -1441,7 +1445,13 @@ extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w
   if (conv_first_ok(g, nullptr, ep && ep->mfma_f16)) {
     // (the slot count ali_conv_mtiles reports depends on the geometry alone: an epilogue the per-image kernel cannot
     // serve is an error here rather than a silent change of the partial layout)
-    if (conv_first_ok(g, ep, false)) return conv_first_launch(g, x, w, y, ep, (hipStream_t)stream);
+    if (conv_first_ok(g, ep, false)) {
+      if (ep && ep->bn_part && ep->bn_slots > 0 && ep->bn_slots != g->B) {
+        set_error("ali_conv_fwd: bn_part was sized for %d slots, the per-image kernel leaves %d", ep->bn_slots, g->B);
+        return ALI_ERR_BAD_ARG;
+      }
+      return conv_first_launch(g, x, w, y, ep, (hipStream_t)stream);
+    }
     if (ep && ep->bn_part) { set_error("ali_conv_fwd: epilogue not supported for this first-layer geometry"); return ALI_ERR_BAD_ARG; }
     // (no partials requested: the GEMM kernel serves the epilogue the per-image kernel cannot)
   }

@@ -990,7 +990,11 @@ static void wgrad_tile(const AliConvGeom* g, bool fast, bool f16, int& bm, int& 
   bm = 128;
   if (!fast) return;
   const int Mtot = g->R * g->S * g->C;
-  const long long npix = (long long)g->B * g->P * g->Q;
+  const long long npix = (long long)g->B * g->P * g->Q * (tuning().tile_m_scale > 0 ? tuning().tile_m_scale : 1);
+  if (tuning().wbm > 0 && tuning().wbn > 0) {   // forced (tests): any of the instantiated variants
+    const int fm = tuning().wbm, fn = tuning().wbn;
+    if ((fm == 64 && fn == 64) || (fm == 128 && (fn == 128 || fn == 64 || fn == 32))) { bm = fm; bn = fn; return; }
+  }
   // more, smaller tiles while the grid is shallow (see gconv.hip: waits are only hidden by co-resident waves)
   const long long b64 = (long long)((Mtot + 63) / 64) * ((g->K + 63) / 64);
   // ... but a long pixel reduction (spectrogram layers) re-reads both operands once per tile pair: larger tiles,

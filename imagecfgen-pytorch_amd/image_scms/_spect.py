@@ -193,7 +193,13 @@ class WaveformData:
         self._front = None
         self._stats = None
 
-    def fuse_spect_to_img(self, mean, std, stds_kept=3.0):
+    def fuse_spect_to_img(self, mean, std=None, stds_kept=3.0):
+        """``fuse_spect_to_img(None)`` returns the stream to plain log-spectrograms (what every other consumer of the
+        source -- a second ``train``, validation, the fine-tuning scripts that apply ``spect_to_img`` themselves --
+        expects)."""
+        if mean is None:
+            self._stats = None
+            return
         self._stats = (mean.reshape(-1).float(), std.reshape(-1).float(), float(stds_kept))
 
     def spectrogram(self, wave):
@@ -241,9 +247,10 @@ def is_data_source(obj):
     return hasattr(obj, "stream") and hasattr(obj, "data")
 
 
-def spectrogram_statistics(stream_fn, device):
+def spectrogram_statistics(stream_fn, device, clamp_variance=True):
     """The statistics pass in front of every spectrogram training loop (audio_mnist.py:347-359): per-last-index mean
-    and standard deviation of the log-spectrograms, averaged over batches."""
+    and standard deviation of the log-spectrograms, averaged over batches.  ``clamp_variance=False`` is the reference's
+    statement as written, ``sqrt(E[X^2] - E[X]^2)``: bit-identical to it, NaN included (see below)."""
     mean, ss, n = 0, 0, 0
     for batch in stream_fn():
         n += 1
@@ -253,7 +260,8 @@ def spectrogram_statistics(stream_fn, device):
     # E[X^2] - E[X]^2 in fp32 cancels catastrophically where a frame is (nearly) constant -- the all-zero frames of the
     # ``pad`` margin -- and the reference's sqrt then returns NaN or a rounding artefact; clamped at 0 here (the only
     # departure from audio_mnist.py:357-359: a NaN column would poison every image of the run)
-    std = torch.sqrt(torch.clamp_min((ss / n).float().to(device) - mean.square(), 0.0))
+    var = (ss / n).float().to(device) - mean.square()
+    std = torch.sqrt(torch.clamp_min(var, 0.0) if clamp_variance else var)
     return mean, std, n
 
 
@@ -263,16 +271,23 @@ def run_training(E, G, D, data, stream_kwargs, attr_keys, n_epochs, l_rate, devi
     (audio_mnist.py:343-420, whalecalls.py:426-499, esrf_acoustic.py:298-379): statistics pass, ``spect_to_img``,
     ALI iterations."""
     stream = lambda: data.stream(**stream_kwargs)  # noqa: E731
-    mean, std, _ = spectrogram_statistics(stream, device)
-    if hasattr(data, "fuse_spect_to_img"):
-        data.fuse_spect_to_img(mean, std, 3.0)          # standardise + clip inside the spectrogram kernel
-        prep = None
-    else:
-        prep = lambda s: torch.clip((s - mean) / (std + 1e-6), -3, 3) / 3.0  # noqa: E731
-    E, G, D, oD, oE, _ = train_on_stream(E, G, D, stream, n_epochs=n_epochs, l_rate=l_rate, device=device,
-                                         preprocess=prep, attr_keys=attr_keys, attr_cast=attr_cast,
-                                         checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path,
-                                         capture=capture)
+    fused = hasattr(data, "fuse_spect_to_img")
+    if fused:
+        data.fuse_spect_to_img(None)                    # the statistics are those of the LOG-spectrograms, whatever an
+    mean, std, _ = spectrogram_statistics(stream, device)   # earlier run left fused into the source
+    try:
+        if fused:
+            data.fuse_spect_to_img(mean, std, 3.0)      # standardise + clip inside the spectrogram kernel
+            prep = None
+        else:
+            prep = lambda s: torch.clip((s - mean) / (std + 1e-6), -3, 3) / 3.0  # noqa: E731
+        E, G, D, oD, oE, _ = train_on_stream(E, G, D, stream, n_epochs=n_epochs, l_rate=l_rate, device=device,
+                                             preprocess=prep, attr_keys=attr_keys, attr_cast=attr_cast,
+                                             checkpoint_every=checkpoint_every, checkpoint_path=checkpoint_path,
+                                             capture=capture)
+    finally:
+        if fused:
+            data.fuse_spect_to_img(None)                # the caller's source streams log-spectrograms again
     return E, G, D, oD, oE
 
 

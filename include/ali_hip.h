@@ -113,6 +113,10 @@ typedef struct {
    * layer's 5 planes in an 8-channel NHWC tensor, mnist.py:108); the others must be zero in x or in w_kxc.  A hint:
    * 0 = unknown; kernels that can skip the padding do. */
   int32_t in_ch_live;
+  /* Capacity check of bn_part: the number of slots the caller sized it for (what ali_conv_mtiles told it); a launch
+   * whose M-tile count differs (tuning reloaded in between, other precision) fails with ALI_ERR_BAD_ARG instead of
+   * writing out of bounds.  0 = unchecked. */
+  int32_t bn_slots;
 } AliEpilogue;
 
 /* A weight-gradient launch that splits the pixel range writes S partial results ("slabs") into its workspace and

@@ -205,6 +205,67 @@ def test_audio_train_entry_point_matches_oracle_loop_on_cpu(tmp_path):
     assert sd["optimizer_D"]["state"][0]["step"] == 4
 
 
+def test_data_source_is_not_left_standardised_and_statistics_match_the_reference_statement():
+    """(i) ``run_training`` fuses ``spect_to_img`` into the source's stream while it trains and must hand the source
+    back streaming log-spectrograms: a second ``train`` on the same object (or a validation / fine-tuning consumer that
+    standardises itself, finetune_audio_mnist_bigan.py) would otherwise compute its statistics on already-standardised
+    images.  (ii) ``spectrogram_statistics(clamp_variance=False)`` is audio_mnist.py:347-359 as written,
+    bit for bit, on a waveform without constant frames (pad = 0: no all-zero margin); with the default clamp only
+    negative rounding noise changes (NaN -> 0)."""
+    import image_scms.audio_mnist as pm
+    from image_scms import _spect
+    n, bs = 4, 2
+    g = torch.Generator().manual_seed(9)
+    wave = torch.randn(n, 8000, generator=g)
+    attrs = {k: torch.nn.functional.one_hot(torch.randint(0, v, (n,), generator=g), v).float()
+             for k, v in pm.ATTRIBUTE_DIMS.items()}
+    data = _spect.WaveformData(wave, attrs, **pm.STFT, device="cpu")
+    stream = lambda: data.stream(batch_size=bs, shuffle=False)     # noqa: E731
+    before = [b["audio"].clone() for b in stream()]
+    seen = []
+    real = _spect.train_on_stream
+
+    def fake_train(E, G, D, stream_fn, **kw):            # the loop itself is covered elsewhere: record what it is fed
+        seen.append([b["audio"].clone() for b in stream_fn()])
+        return E, G, D, None, None, []
+    _spect.train_on_stream = fake_train
+    try:
+        stats = []
+        for _ in range(2):
+            real_stats = _spect.spectrogram_statistics
+
+            def spy(fn, dev, **kw):
+                out = real_stats(fn, dev, **kw)
+                stats.append(out)
+                return out
+            _spect.spectrogram_statistics = spy
+            try:
+                _spect.run_training(None, None, None, data, dict(batch_size=bs, shuffle=False), (), 1, 1e-4, "cpu")
+            finally:
+                _spect.spectrogram_statistics = real_stats
+    finally:
+        _spect.train_on_stream = real
+    assert torch.equal(stats[0][0], stats[1][0]) and torch.equal(stats[0][1], stats[1][1])   # same statistics twice
+    assert all(torch.equal(a, b) for a, b in zip(seen[0], seen[1]))
+    assert seen[0][0].abs().max().item() <= 1.0                                            # training saw images ...
+    after = [b["audio"] for b in stream()]
+    assert all(torch.equal(a, b) for a, b in zip(before, after))                           # ... the caller sees spectra
+    # (ii) the reference's statement, un-clamped, on spectrograms without constant frames
+    src = _spect.WaveformData(wave, attrs, n_fft=255, win_length=128, pad=0, device="cpu")
+    sfn = lambda: src.stream(batch_size=bs, shuffle=False)         # noqa: E731
+    mean, ss, nb = 0, 0, 0
+    for batch in sfn():                                    # audio_mnist.py:347-359
+        nb += 1
+        mean = mean + batch["audio"].mean(dim=(0, 1)).reshape((1, 1, -1))
+        ss = ss + batch["audio"].square().mean(dim=(0, 1)).reshape((1, 1, -1))
+    mean = (mean / nb).float()
+    std = torch.sqrt((ss / nb).float() - mean.square())
+    m0, s0, _ = _spect.spectrogram_statistics(sfn, "cpu", clamp_variance=False)
+    assert torch.equal(m0, mean) and torch.equal(s0, std) and not torch.isnan(std).any()
+    m1, s1, _ = _spect.spectrogram_statistics(sfn, "cpu")
+    assert torch.equal(m1, mean) and torch.equal(s1, std)          # the clamp is inert where the variance is positive
+
+
 def test_mnist_checkpoint_and_load_model_on_cpu(tmp_path):
     """mnist.train(checkpoint_every=...) -> mnist.load_model (reference mnist.py:302-313) round trip."""
     import image_scms.mnist as pm
