@@ -19,13 +19,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "imagecfgen-pytorch_amd"))
 
 BS_PER_GPU = 512
-# algorithmic work per image of the minimal schedule at B=512 (fp32 storage)
-ALG_BYTES_PER_IMG = 8108239.0
-ALG_FLOP_PER_IMG = 1.0026e9
+# SURVEY.md 8(d) / BASELINE.md 3: algorithmic work per image of the minimal schedule at the config's per-GPU batch (fp32
+# storage): (bytes / image, FLOP / image)
+STEP_WORK = {"mnist": (8108239.0, 1.0026e9), "audio": (102121035.0, 3.0046e10), "whale": (335299959.0, 9.8432e10),
+             "esrf": (1946750058.0, 6.0378e11)}
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_CSV = "profiles/r02_pmc_hbm_traffic_bs512.csv"
+# committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of `python bench.py --workload W --precision P` (scratch/collect_profiles.sh)
+TRAFFIC_CSV = "profiles/r03_pmc_hbm_traffic_{workload}_{precision}.csv"
 
 
 def synth_batch(bs, device, seed):
@@ -184,27 +186,64 @@ def main():
     for i in range(args.steps):
         r = one(args.warmup + i)
     fence()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     losses = {k: float(v) for k, v in r.items()}
 
-    # ---- roofline leg: one instrumented eager iteration on every rank (collectives stay matched),
-    # HIP events around every GEMM launch on rank 0
+    # ---- roofline leg: ONE instrumented eager iteration on every rank (collectives stay matched); on rank 0 every GEMM
+    # launch is timed once, in sequence, with HIP events on the launch stream (ops.KernelProfile).  The stream is kept
+    # busy with replays of the timed region's own iteration while the host enqueues the instrumented one, so its kernels
+    # run back to back and at steady-state clocks; the event / dispatch overhead of an interval is calibrated on spin
+    # kernels of known length, behind the same kind of busy stream, and subtracted.
     prof = ops.KernelProfile()
-    if args.mode == "stepper":
-        keep, stepper.capture = stepper.capture, False
-    one(0)                      # un-instrumented eager pass first (code objects / allocator warm for this mode)
+    step_ms = dt_local / args.steps * 1e3
+    graph_mode = args.mode == "stepper" and not args.no_graph
+
+    def eager(i):
+        if args.mode == "stepper":
+            keep, stepper.capture = stepper.capture, False
+        try:
+            return one(i)
+        finally:
+            if args.mode == "stepper":
+                stepper.capture = keep
+
+    def busy(ms):
+        """enqueue about ``ms`` milliseconds of the timed region's own work (same on every rank)"""
+        if graph_mode:
+            for i in range(int(ms / step_ms) + 1):
+                one(i)
+        elif rank == 0:
+            prof.hold(ms)
+
+    eager(0)                    # un-instrumented eager pass first (code objects / allocator warm for this mode) ...
     fence()
+    th = time.perf_counter()
+    eager(1)                    # ... and one to learn how long the host needs to enqueue an iteration
+    host_ms = (time.perf_counter() - th) * 1e3
+    fence()
+    cover = min(2.5 * host_ms + 20.0, 1500.0)
+    if rank == 0:
+        prof.spin_rate()
+    if rank == 0 or graph_mode:
+        busy(30.0)
+    if rank == 0:
+        prof.calibrate(busy=lambda: None)          # (the stream is busy already)
+    busy(cover)
     if rank == 0:
         ops.set_profile(prof)
-    one(1)
+    eager(2)
     ops.set_profile(None)
-    if args.mode == "stepper":
-        stepper.capture = keep
     fence()
+    rank_ms = [dt_local / args.steps * 1e3]
+    if world > 1:
+        t = torch.tensor(rank_ms, device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        rank_ms = [float(v.item()) for v in allr]
 
     out = None
     if rank == 0:
@@ -212,19 +251,24 @@ def main():
         value = bs * world * args.steps / dt
         per_gpu = value / world
         fam = prof.summary() if prof.records else {}
-        if "gconv_t" in fam:       # conv-forward and transposed/dgrad launches are the same kernel
-            g0 = fam.setdefault("gconv", {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
-            for k in g0:
-                g0[k] += fam["gconv_t"][k]
-            del fam["gconv_t"]
+        for src, dst in (("gconv_t", "gconv"), ("wgrad_multi", "wgrad")):
+            # conv-forward and transposed / data-gradient launches are one kernel; so are the weight-gradient GEMMs
+            # launched alone and the jobs of a combined launch (wgrad_fast_kernel / wgrad_fast_multi_kernel)
+            if src in fam:
+                g0 = fam.setdefault(dst, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
+                for k in g0:
+                    g0[k] += fam[src][k]
+                del fam[src]
+        traffic_csv = TRAFFIC_CSV.format(workload=args.workload, precision=args.precision)
+
         def pmc_traffic(kernel_substr):
-            """HBM bytes per launch of a kernel family from the COMMITTED rocprofv3 PMC passes of this workload
-            (TRAFFIC_CSV: FETCH_SIZE / WRITE_SIZE in KB per launch, separate passes of the same command; on gfx950
-            FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md).  Counters cannot be read from inside
-            the timed process: the figure is a property of the kernels at the benched shapes, not of this run -- the
-            JSON says so in ``traffic_source``.  None if no pass covers this workload / precision."""
-            path = os.path.join(ROOT, TRAFFIC_CSV)
-            if args.workload != "mnist" or args.precision != "f32" or not os.path.exists(path):
+            """HBM bytes per launch of a kernel family from the COMMITTED rocprofv3 PMC passes of this command
+            (FETCH_SIZE / WRITE_SIZE in KB per launch, separate --pmc passes; on gfx950 FETCH_SIZE reports half of wide
+            coalesced reads, MI355X_MICROARCH.md).  Counters cannot be read from inside the timed process: the figure
+            is a property of the kernels at the benched shapes, not of this run -- ``traffic_source`` says so.  None if
+            no committed pass covers this workload / precision."""
+            path = os.path.join(ROOT, traffic_csv)
+            if world != 1 or args.mode != "stepper" or not os.path.exists(path):
                 return None
             n = tot = 0.0
             for line in open(path):
@@ -236,25 +280,33 @@ def main():
             return round(tot / n) if n else None
 
         roof = None
+        f16 = args.precision == "f16"
         if fam:
-            name = max(fam, key=lambda k: fam[k]["ms"])
+            gemm = [k for k in fam if k in ("gconv", "wgrad")] or list(fam)
+            name = max(gemm, key=lambda k: fam[k]["ms"])
             f = fam[name]
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
-            ksub = {"gconv": "gconv_kernel", "wgrad": "wgrad_fast_kernel"}
+            peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+            ksub = {"gconv": "gconv_kernel", "wgrad": "wgrad_fast"}
 
             def pair(k):      # algorithmic bytes next to the counters' traffic, per launch, for one kernel family
                 v = fam[k]
                 return {"alg_bytes_per_launch": round(v["bytes"] / v["launches"]), "traffic": pmc_traffic(ksub[k])}
 
-            roof = {"bound": "mfma", "kernel": {"gconv": "ali::gconv_kernel", "wgrad": "ali::wgrad_fast_kernel"}[name],
+            traffic = pmc_traffic(ksub.get(name, name))
+            roof = {"bound": "mfma", "kernel": {"gconv": "ali::gconv_kernel", "wgrad": "ali::wgrad_fast_kernel"}.get(name, name),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": pmc_traffic(ksub[name]),
-                    "traffic_source": TRAFFIC_CSV + " (committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command;"
-                                      " not measured in this run)" if pmc_traffic(ksub[name]) is not None else None,
+                    "traffic": traffic,
+                    "traffic_source": (traffic_csv + " (committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command;"
+                                       " not measured in this run)") if traffic is not None else None,
                     "alg_bytes_per_launch": round(f["bytes"] / f["launches"]),
                     "alg_flop_per_launch": round(f["flops"] / f["launches"]),
                     "launches_per_step": f["launches"], "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2),
+                    "method": "every launch of one eager iteration timed once, in sequence, [e0] k [e1] with HIP events on "
+                              "the launch stream, which is kept busy with replays of the timed iteration while the host "
+                              "enqueues (back-to-back execution at steady-state clocks); minus the interval's event/dispatch "
+                              "overhead calibrated on spin kernels; algorithmic FLOP on live channels",
+                    "event_overhead_us": round(prof.overhead_ms * 1e3, 2),
                     "families": {k: dict({"launches": v["launches"], "ms": round(v["ms"], 3),
                                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)},
                                          **(pair(k) if k in ksub else {})) for k, v in fam.items()}}
@@ -262,6 +314,14 @@ def main():
                  "audio": "image_scms/audio_mnist.py ALI iteration, AudioMNIST log-spectrogram 128x128x1",
                  "whale": "image_scms/whalecalls.py BiGAN iteration, whale-call spectrogram 256x256x1",
                  "esrf": "image_scms/esrf_acoustic.py ALI iteration, ESRF spectrogram 512x512x1"}
+        arith = "fp16 MFMA (fp32 accumulate, fp32 master weights)" if f16 else "fp32 MFMA"
+        alg_bytes, alg_flop = STEP_WORK[args.workload]
+        step_roof = {"hbm_frac": round(per_gpu * alg_bytes / (PEAK_HBM_GBS * 1e9), 4),
+                     ("mfma_f16_frac" if f16 else "mfma_f32_frac"):
+                         round(per_gpu * alg_flop / ((PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS) * 1e12), 4),
+                     "alg_bytes_per_img": alg_bytes, "alg_flop_per_img": alg_flop}
+        if bs != (BS_PER_GPU if args.workload == "mnist" else SPECT[args.workload][4]):
+            step_roof = None      # the per-image figures are those of the config's batch (weights / Adam amortised over it)
         out = {
             "metric": "ALI training images/sec (E+G+D step), MorphoMNIST bs=512/GPU" if args.workload == "mnist" else
                       f"ALI training images/sec (E+G+D step), {args.workload} bs={bs}/GPU",
@@ -269,17 +329,14 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{names[args.workload]} synthetic, bs={bs}/GPU, fp32 MFMA, mode={args.mode}"
+            "config": {"workload": f"{names[args.workload]} synthetic, bs={bs}/GPU, {arith}, mode={args.mode}"
                                    f"{'' if args.no_graph or args.mode != 'stepper' else ('+hipgraph' if world == 1 else '+hipgraph-segments')}",
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "roofline": roof,
-            "step_roofline": {"hbm_frac": round(per_gpu * ALG_BYTES_PER_IMG / (PEAK_HBM_GBS * 1e9), 4),
-                              "mfma_f32_frac": round(per_gpu * ALG_FLOP_PER_IMG / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-                              "alg_bytes_per_img": ALG_BYTES_PER_IMG, "alg_flop_per_img": ALG_FLOP_PER_IMG},
+            "step_roofline": step_roof,
+            "ms_per_step_ranks": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "losses_last_step": losses,
         }
-        if args.workload != "mnist":
-            out["step_roofline"] = None          # SURVEY 8(d) per-image figures of the other configs: see DESIGN.md
         if world == 1 and not args.no_cpu_baseline and args.workload == "mnist":
             out["cpu_baseline"] = cpu_baseline(bs)
             if bs != 64:      # BASELINE.json configs[0]: the reference's own CPU-runnable case

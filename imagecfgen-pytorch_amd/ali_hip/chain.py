@@ -494,7 +494,7 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             Co = m.out_channels
             contrib = torch.empty(B, H, W, Co * R * S, dtype=torch.float32, device=cur.device)
             ops.conv_fwd(ops.geom(B, H, W, Cp, H, W, Co * R * S, 1, 1, 1, 0), t, plan.packed(st, "scatter", Cp), contrib,
-                         ops.epilogue())
+                         ops.epilogue(), live=(c_log, None))
             ops.col2im(contrib, Co * R * S, plan.packed_bias(st), y, B, H, W, out_shape[1], out_shape[2], Co, Co, R, S,
                        m.stride[0], m.padding[0], st.act, st.slope)
         elif _is_tconv1(st, Cp):
@@ -502,9 +502,9 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             ops.tconv1_fwd(t, plan.packed(st, "fwd", Cp), plan.packed_bias(st), y, B, H, W, Cp, m.kernel_size[0],
                            m.kernel_size[1], m.padding[0], 1, st.act, st.slope)
         elif st.kind == "convT":
-            ops.conv_bwd_data(g, t, plan.packed(st, "fwd", Cp), y, ep)
+            ops.conv_bwd_data(g, t, plan.packed(st, "fwd", Cp), y, ep, live=(None, c_log))
         else:
-            ops.conv_fwd(g, t, plan.packed(st, "fwd", Cp), y, ep, out_ld=out_ld)
+            ops.conv_fwd(g, t, plan.packed(st, "fwd", Cp), y, ep, out_ld=out_ld, live=(c_log, None))
         sv.t, sv.y, sv.geom, sv.in_shape, sv.out_shape = t, y, g, (B, H, W, Cp), out_shape
         if save:
             saved.append(sv)
@@ -654,9 +654,9 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             ops.tconv1_dgrad(g_pre, 1, plan.packed(st, "fwd", Cp), sv.x_in if pact != ACT_NONE else None, pact, pslope,
                              gt, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1], m.padding[0])
         elif st.kind == "convT":
-            ops.conv_fwd(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep)
+            ops.conv_fwd(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep, live=(None, c_in_log))
         else:
-            ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep, in_ld=ld)
+            ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep, in_ld=ld, live=(c_in_log, None))
         if sv.bn is not None:
             bn = sv.bn
             use_batch = sv.training or bn.running_mean is None

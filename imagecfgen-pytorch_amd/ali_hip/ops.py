@@ -154,25 +154,79 @@ def conv_mtiles(g: AliConvGeom, which: int):
 
 
 class KernelProfile:
-    """Live per-launch timing of the GEMM kernels with HIP events on the launch stream (bench.py's roofline leg).
-    Each record: (family, algorithmic flops, (e0, e1, e2), shape); see ``_launch`` for what the events bracket."""
+    """Live timing of the GEMM / direct kernel launches of ONE eager iteration with HIP events on the launch stream
+    (bench.py's roofline leg).  Every launch is timed once, where it runs in the iteration: ``[e0] k [e1]``.
+
+    What makes that interval the kernel's duration as a rocprofv3 kernel trace reports it (checked against the trace of
+    the same process: 4.764 vs 4.770 ms for the 88 GEMM launches of a MorphoMNIST iteration):
+      * the caller keeps the stream busy with real work (graph replays of the same iteration) while the host enqueues
+        the instrumented one, so its launches execute back to back -- as in a replay -- and at the clocks of the timed
+        region (behind an idle or spin-waiting stream the chip clocks down: the same kernels then ran 10 % longer);
+      * ``calibrate()`` measures what an ``[e0] k [e1]`` interval contains besides the kernel -- event markers plus
+        dispatch latency -- as the zero-length intercept of spin kernels of two known lengths timed the same way, and
+        that overhead is subtracted from every record (3.4 us plain, 5.7 us under rocprofv3).
+    (An event pair attached to the dispatch itself, hipExtLaunchKernelGGL, was tried instead: its interval is 4.5 us
+    LONGER than the trace's duration per launch, and it needs library support; dropped.)
+    Each record: (family, algorithmic flops, algorithmic bytes, (e0, e1), shape)."""
 
     def __init__(self):
         self.records = []
+        self.overhead_ms = 0.0
+        self.spin_cycles_per_ms = None
 
     @staticmethod
-    def _ms(ev):
-        e0, e1, e2 = ev
-        return max(e1.elapsed_time(e2) - e0.elapsed_time(e1), 1e-4)
+    def _spin_pair(cycles):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(int(cycles))
+        e1.record()
+        return e0, e1
+
+    def spin_rate(self):
+        if self.spin_cycles_per_ms is None:
+            torch.cuda.synchronize()
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            torch.cuda._sleep(20_000_000)
+            t1.record()
+            torch.cuda.synchronize()
+            self.spin_cycles_per_ms = 20_000_000 / max(t0.elapsed_time(t1), 1e-3)
+        return self.spin_cycles_per_ms
+
+    def calibrate(self, busy=None, reps=24):
+        """overhead_ms = the part of an ``[e0] k [e1]`` interval that is not the kernel.  ``busy()`` (optional) enqueues
+        real work first, so that the pairs are measured behind a busy stream like the iteration itself."""
+        rate = self.spin_rate()
+        short, long_ = int(0.02 * rate), int(0.10 * rate)          # 20 us, 100 us
+        if busy is not None:
+            busy()
+        else:
+            torch.cuda._sleep(int(20.0 * rate))
+        pairs = [(self._spin_pair(short), self._spin_pair(long_)) for _ in range(reps)]
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for (a, b), _ in pairs)[reps // 2]
+        tl = sorted(a.elapsed_time(b) for _, (a, b) in pairs)[reps // 2]
+        slope = (tl - ts) / (long_ - short)                       # ms per spin cycle
+        self.overhead_ms = max(ts - slope * short, 0.0)
+        return self.overhead_ms
+
+    def hold(self, ms):
+        """park the current stream for about ``ms`` milliseconds behind a spin kernel (fallback when the caller has no
+        real work to keep the stream busy with: the chip clocks down meanwhile)"""
+        torch.cuda._sleep(int(ms * self.spin_rate()))
+
+    def _ms(self, ev):
+        e0, e1 = ev
+        return max(e0.elapsed_time(e1) - self.overhead_ms, 1e-4)
 
     def _table(self, key):
         torch.cuda.synchronize()
         tab = {}
-        for name, flops, ev, desc in self.records:
+        for name, flops, nbytes, ev, desc in self.records:
             f = tab.setdefault(key(name, desc), {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             f["launches"] += 1
             f["flops"] += flops
-            f["bytes"] += _geom_bytes(desc)
+            f["bytes"] += nbytes
             f["ms"] += self._ms(ev)
         return tab
 
@@ -215,32 +269,30 @@ class launch_hook:
         _HOOK = self.prev
 
 
-def _geom_cost(g: AliConvGeom):
-    """(algorithmic FLOP, shape key) of one GEMM launch; algorithmic bytes (both activations + the weights once) are
-    ``_geom_bytes``."""
-    return (2.0 * g.B * g.P * g.Q * g.K * g.C * g.R * g.S,
+def _geom_cost(g: AliConvGeom, live=None):
+    """(algorithmic FLOP, algorithmic bytes, shape key) of one GEMM launch: 2*B*P*Q*K*C*R*S and both activations + the
+    weights once, fp32.  ``live`` = (c, k): the channels of x / y that carry data where a channel stride is padded
+    (5 of 8 image planes, 771 of 800 Generator inputs) -- multiplications by the zero padding are not algorithmic work."""
+    c = live[0] if (live and live[0]) else g.C
+    k = live[1] if (live and live[1]) else g.K
+    return (2.0 * g.B * g.P * g.Q * k * c * g.R * g.S,
+            4.0 * (g.B * g.H * g.W * c + g.B * g.P * g.Q * k + k * c * g.R * g.S),
             (g.B, g.H, g.W, g.C, g.P, g.Q, g.K, g.R, g.stride, g.pad))
 
 
-def _geom_bytes(desc):
-    B, H, W, C, P, Q, K, R, stride, pad = desc
-    return 4.0 * (B * H * W * C + B * P * Q * K + K * C * R * R) if B else 0.0
+_NO_SHAPE = (0,) * 10
 
 
-def _launch(name, flops, desc, fn):
-    """Run one kernel launch.  Under a KernelProfile it is issued three times between three event records,
-    [e0] fn [e1] fn fn [e2]: both intervals carry the same event-marker latency, so (e2 - e1) - (e1 - e0) is the
-    duration of one launch as it runs back to back with its neighbours (every launch on this path is idempotent)."""
+def _launch(name, cost, fn):
+    """Run one kernel launch; under a KernelProfile bracket it with two event records (see KernelProfile).
+    ``cost`` = (algorithmic flops, algorithmic bytes, shape key)."""
     if _PROFILE is None:
         return fn()
-    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
-    fn()
-    fn()
-    e2.record()
-    _PROFILE.records.append((name, flops, (e0, e1, e2), desc))
+    _PROFILE.records.append((name, cost[0], cost[1], (e0, e1), cost[2]))
 
 
 def shadow16(t):
@@ -334,9 +386,10 @@ def _view_ptr(t, ld, name):
     return _ptr(t) if ld else _chk(t, name)
 
 
-def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue, in_ld=0, out_ld=0):
+def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue, in_ld=0, out_ld=0, live=None):
     """``in_ld`` / ``out_ld`` > 0: ``x`` / ``y`` are column ranges (strided views) of wider row-major buffers whose
-    pixels are that many floats apart (AliEpilogue.in_ld / out_ld)."""
+    pixels are that many floats apart (AliEpilogue.in_ld / out_ld).  ``live`` = (channels of x, channels of y) that
+    carry data when a stride is padded: accounting only (``_geom_cost``)."""
     lib = _lib.load()
     ws = workspace(x.device)
     ep.in_ld, ep.out_ld = in_ld, out_ld
@@ -347,13 +400,13 @@ def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue, in_ld=0, out_ld=0)
         _lib.check(lib.ali_conv_fwd(byref(g), _view_ptr(x, in_ld, "x"), _chk(w_packed, "w"), _view_ptr(y, out_ld, "y"),
                                     byref(ep),
                                     c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
-    _launch("gconv", *_geom_cost(g), go)
+    _launch("gconv", _geom_cost(g, live), go)
     if _HOOK is not None:
         _HOOK.gemm("fwd", g, x, w_packed, y, ep, in_ld, out_ld)
     return y
 
 
-def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue, in_ld=0, out_ld=0):
+def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue, in_ld=0, out_ld=0, live=None):
     lib = _lib.load()
     ws = workspace(dy.device)
     ep.in_ld, ep.out_ld = in_ld, out_ld
@@ -364,7 +417,7 @@ def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue, in_ld=0, ou
         _lib.check(lib.ali_conv_bwd_data(byref(g), _view_ptr(dy, in_ld, "dy"), _chk(w_packed, "w"),
                                          _view_ptr(dx, out_ld, "dx"), byref(ep),
                                          c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
-    _launch("gconv_t", *_geom_cost(g), go)
+    _launch("gconv_t", _geom_cost(g, live), go)
     if _HOOK is not None:
         _HOOK.gemm("bwd_data", g, dy, w_packed, dx, ep, in_ld, out_ld)
     return dx
@@ -416,6 +469,7 @@ class FoldQueue:
         self.keep = []          # ... and the tensors they read / write, alive until flush
         self.off = 0
         self.flops = 0.0
+        self.bytes = 0.0
         self.n_jobs = 1         # deferrable launches of the pass in progress (expect()): what a combined launch will hold
         self.after_flush = []   # launch_hook callbacks of deferred weight gradients (tests)
 
@@ -433,7 +487,7 @@ class FoldQueue:
 
     def abandon(self):
         """forget recorded work without launching it (an iteration that raised half-way)"""
-        self.jobs, self.launches, self.keep, self.flops, self.off = [], [], [], 0.0, 0
+        self.jobs, self.launches, self.keep, self.flops, self.bytes, self.off = [], [], [], 0.0, 0.0, 0
         self.after_flush = []
 
     def split_target(self):
@@ -447,15 +501,15 @@ class FoldQueue:
 
             def go_l():
                 _lib.check(_lib.load().ali_wgrad_launch_multi(n, arr, _stream()), "ali_wgrad_launch_multi")
-            _launch("wgrad_multi", self.flops, (0,) * 10, go_l)
-        self.launches, self.keep, self.flops = [], [], 0.0
+            _launch("wgrad_multi", (self.flops, self.bytes, _NO_SHAPE), go_l)
+        self.launches, self.keep, self.flops, self.bytes = [], [], 0.0, 0.0
         if self.jobs:
             arr = (_lib.AliWgradFold * len(self.jobs))(*self.jobs)
             n = len(self.jobs)
 
             def go():
                 _lib.check(_lib.load().ali_wgrad_fold_multi(n, arr, _stream()), "ali_wgrad_fold_multi")
-            _launch("wgrad_fold", 0.0, (0,) * 10, go)
+            _launch("wgrad_fold", (0.0, 0.0, _NO_SHAPE), go)
         self.jobs, self.off = [], 0
         todo, self.after_flush = self.after_flush, []
         for fn in todo:
@@ -479,8 +533,8 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
         left = arena.numel() * 4 - defer.off
         if left >= (32 << 20):                    # a region of its own (else: the shared workspace, immediate fold)
             ws_ptr, ws_n, job = arena.data_ptr() + defer.off, left, _lib.AliWgradFold()
-            if _PROFILE is None and DEFER_WGRAD_LAUNCH:
-                lj = _lib.AliWgradJob()           # (a KernelProfile times every GEMM on its own)
+            if DEFER_WGRAD_LAUNCH:
+                lj = _lib.AliWgradJob()
 
     def go():
         _lib.check(lib.ali_conv_bwd_weight(byref(g), _chk(x, "x"), _ptr(dy) if dy_ld else _chk(dy, "dy"),
@@ -492,14 +546,23 @@ def conv_bwd_weight(g: AliConvGeom, x, dy, dst, cg_log, cd_log, s_dc, s_gc, s_ta
                                            None if job is None else byref(job), None if lj is None else byref(lj),
                                            0 if lj is None else defer.split_target(),
                                            c_void_p(ws_ptr), ws_n, _stream()), "ali_conv_bwd_weight")
+    cost = _geom_cost(g, (cg_log, cd_log))
     if lj is None:
-        _launch("wgrad", *_geom_cost(g), go)
-    else:
+        _launch("wgrad", cost, go)
+    else:                     # records the job, or -- a launch of another kind (large tiles, fp16) -- runs it right away
+        ev = None
+        if _PROFILE is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         go()
         if lj.opaque[0] == 1:
             defer.launches.append(lj)
             defer.keep.append((x, dy, dst, db, tab))
-            defer.flops += _geom_cost(g)[0]
+            defer.flops += cost[0]
+            defer.bytes += cost[1]
+        elif ev is not None:
+            ev[1].record()
+            _PROFILE.records.append(("wgrad", cost[0], cost[1], ev, cost[2]))
     deferred = job is not None and job.S > 0
     if deferred:
         defer.jobs.append(job)
@@ -531,7 +594,7 @@ def tconv1_fwd(big, w_tk, bias, out, B, P, Q, K, R, S, pad, ostride, act, slope,
                                       None if rowscale is None else _ptr(rowscale),
                                       0 if rowscale is None else rowscale.stride(0), _stream()),
                    "ali_tconv1_fwd")
-    _launch("tconv1_fwd", 2.0 * B * P * Q * K * R * S, (0,) * 10, go)
+    _launch("tconv1_fwd", (2.0 * B * P * Q * K * R * S, 4.0 * B * (P * Q * K + (P + R - 1 - 2 * pad) * (Q + S - 1 - 2 * pad)), _NO_SHAPE), go)
     return out
 
 
@@ -541,7 +604,7 @@ def tconv1_dgrad(small, sstride, w_tk, dact_y, dact, dslope, gbig, B, P, Q, K, R
     def go():
         _lib.check(lib.ali_tconv1_dgrad(_ptr(small), sstride, _chk(w_tk, "w"), _opt(dact_y), dact, dslope,
                                         _chk(gbig, "gbig"), B, P, Q, K, R, S, pad, _stream()), "ali_tconv1_dgrad")
-    _launch("tconv1_dgrad", 2.0 * B * P * Q * K * R * S, (0,) * 10, go)
+    _launch("tconv1_dgrad", (2.0 * B * P * Q * K * R * S, 4.0 * B * (2 * P * Q * K + (P + R - 1 - 2 * pad) * (Q + S - 1 - 2 * pad)), _NO_SHAPE), go)
     return gbig
 
 
@@ -553,7 +616,7 @@ def tconv1_wgrad(big, small, sstride, nc, dw, s_k, s_tap, s_c, B, P, Q, K, R, S,
         _lib.check(lib.ali_tconv1_wgrad(_chk(big, "big"), _ptr(small), sstride, nc, _ptr(dw), s_k, s_tap, s_c, B, P,
                                         Q, K, R, S, pad, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
                    "ali_tconv1_wgrad")
-    _launch("tconv1_wgrad", 2.0 * B * P * Q * K * R * S * nc, (0,) * 10, go)
+    _launch("tconv1_wgrad", (2.0 * B * P * Q * K * R * S * nc, 4.0 * B * (P * Q * K + nc * (P + R - 1 - 2 * pad) * (Q + S - 1 - 2 * pad)), _NO_SHAPE), go)
     return dw
 
 
