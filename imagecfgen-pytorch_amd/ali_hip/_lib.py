@@ -42,6 +42,10 @@ class AliWgradJob(Structure):
     _fields_ = [("opaque", c_uint64 * 40)]
 
 
+class AliGemmJob(Structure):
+    _fields_ = [("opaque", c_uint64 * 112)]
+
+
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol include/ali_hip.h declares
@@ -57,6 +61,11 @@ SIGNATURES = {
     "ali_conv_bwd_weight": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                       POINTER(AliWgradFold), POINTER(AliWgradJob), c_int32, c_void_p, c_size_t, c_void_p]),
+    "ali_conv_fwd_job": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue), c_void_p,
+                                   c_size_t, POINTER(AliGemmJob), c_void_p]),
+    "ali_conv_bwd_data_job": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue),
+                                        c_void_p, c_size_t, POINTER(AliGemmJob), c_void_p]),
+    "ali_gemm_launch_multi": (c_int32, [c_int32, POINTER(AliGemmJob), c_void_p]),
     "ali_wgrad_deferrable": (c_int32, [POINTER(AliConvGeom), c_int32]),
     "ali_wgrad_launch_multi": (c_int32, [c_int32, POINTER(AliWgradJob), c_void_p]),
     "ali_wgrad_fold_multi": (c_int32, [c_int32, POINTER(AliWgradFold), c_void_p]),

@@ -381,9 +381,50 @@ def join_ok(plan: ChainPlan) -> bool:
             and st.mod.out_channels % 4 == 0 and st.mod.in_channels % 4 == 0)
 
 
-def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool, groups: int = 1,
-                  join=None, first_mask_applied: bool = False):
-    """x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list).
+def drive(gen):
+    """run a chain generator to its end on its own (every GEMM is launched where it is requested)"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
+def run_parallel(*gens):
+    """Advance independent chain generators in lock step, one GEMM each per round, and issue the GEMMs of a round as
+    ONE multi-job launch per kernel variant (``ops.gemm_batch``).  A chain generator (``chain_forward_gen``,
+    ``chain_backward_gen``, or a generator that ``yield from``-s several of them) yields right after each GEMM request
+    and before anything that reads its result, so whatever else it launches between two yields only depends on GEMMs
+    of earlier rounds.  The generators must not depend on each other.  Returns their return values."""
+    res = [None] * len(gens)
+    live = list(range(len(gens)))
+    while live:
+        nxt = []
+        with ops.gemm_batch():
+            for i in live:
+                try:
+                    next(gens[i])
+                    nxt.append(i)
+                except StopIteration as e:
+                    res[i] = e.value
+        live = nxt
+    return res
+
+
+def chain_forward(*args, **kwargs):
+    """``chain_forward_gen`` run on its own: returns (y_last, saved list)."""
+    return drive(chain_forward_gen(*args, **kwargs))
+
+
+def chain_backward(*args, **kwargs):
+    """``chain_backward_gen`` run on its own: returns (gx or None, {param tensor id -> grad})."""
+    return drive(chain_backward_gen(*args, **kwargs))
+
+
+def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool, groups: int = 1,
+                      join=None, first_mask_applied: bool = False):
+    """Generator form of the forward pass (see ``run_parallel``): yields after every GEMM request.
+    x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list).
 
     ``join`` = (joint [B, Ctot] fp32, column offset, mask [B, Ctot] or None): the last stage (``join_ok``; output map
     1x1) writes act(conv) * mask[:, off:off+K] into joint[:, off:off+K] instead of a tensor of its own -- the
@@ -495,6 +536,7 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
             contrib = torch.empty(B, H, W, Co * R * S, dtype=torch.float32, device=cur.device)
             ops.conv_fwd(ops.geom(B, H, W, Cp, H, W, Co * R * S, 1, 1, 1, 0), t, plan.packed(st, "scatter", Cp), contrib,
                          ops.epilogue(), live=(c_log, None))
+            yield
             ops.col2im(contrib, Co * R * S, plan.packed_bias(st), y, B, H, W, out_shape[1], out_shape[2], Co, Co, R, S,
                        m.stride[0], m.padding[0], st.act, st.slope)
         elif _is_tconv1(st, Cp):
@@ -503,8 +545,10 @@ def chain_forward(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: in
                            m.kernel_size[1], m.padding[0], 1, st.act, st.slope)
         elif st.kind == "convT":
             ops.conv_bwd_data(g, t, plan.packed(st, "fwd", Cp), y, ep, live=(None, c_log))
+            yield
         else:
             ops.conv_fwd(g, t, plan.packed(st, "fwd", Cp), y, ep, out_ld=out_ld, live=(c_log, None))
+            yield
         sv.t, sv.y, sv.geom, sv.in_shape, sv.out_shape = t, y, g, (B, H, W, Cp), out_shape
         if save:
             saved.append(sv)
@@ -518,9 +562,11 @@ def wgrad_geoms(plan: ChainPlan, saved):
     return [sv.geom for st, sv in zip(plan.stages, saved) if not _is_tconv1(st, sv.in_shape[3])]
 
 
-def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True,
-                   grad_dst=None, gx_planes=None, gy_ld: int = 0, gy_pre: bool = False, in_act=None, fold=None):
-    """Returns (gx or None, {param tensor id -> grad}).  ``grad_dst`` optionally maps id(param) to a
+def chain_backward_gen(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need_gx: bool, need_params: bool = True,
+                       grad_dst=None, gx_planes=None, gy_ld: int = 0, gy_pre: bool = False, in_act=None, fold=None):
+    """Generator form of the backward pass (see ``run_parallel``): yields after every data-gradient GEMM request (the
+    weight gradients are deferred to ``fold`` or launched at once: nothing in the chain reads them).
+    Returns (gx or None, {param tensor id -> grad}).  ``grad_dst`` optionally maps id(param) to a
     preallocated destination (a view of a flat gradient buffer) that the kernels write directly.
     ``gx_planes`` (hand-scheduled step only): instead of the full input gradient return only these input
     channels of it, as a [B,H,W,len(gx_planes)] tensor -- the first layer's data gradient is consumed one plane
@@ -624,6 +670,7 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
             contrib = torch.empty(B, P, Q, NP * R * S, dtype=torch.float32, device=gy.device)
             ops.conv_fwd(ops.geom(B, P, Q, K, P, Q, NP * R * S, 1, 1, 1, 0), g_pre,
                          plan.packed(st, ("scatter_dgrad", tuple(gx_planes)), Cp), contrib, ops.epilogue())
+            yield
             planes = torch.empty(B, H, W, NP, dtype=torch.float32, device=gy.device)
             ops.col2im(contrib, NP * R * S, None, planes, B, P, Q, H, W, NP, NP, R, S, m.stride[0], m.padding[0])
             if sv.mask is not None:
@@ -655,8 +702,10 @@ def chain_backward(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, need
                              gt, B, H, W, Cp, m.kernel_size[0], m.kernel_size[1], m.padding[0])
         elif st.kind == "convT":
             ops.conv_fwd(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep, live=(None, c_in_log))
+            yield
         else:
             ops.conv_bwd_data(g, g_pre, plan.packed(st, "dgrad", Cp), gt, ep, in_ld=ld, live=(c_in_log, None))
+            yield
         if sv.bn is not None:
             bn = sv.bn
             use_batch = sv.training or bn.running_mean is None

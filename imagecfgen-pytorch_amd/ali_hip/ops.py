@@ -21,10 +21,11 @@ def set_workspace_bytes(n: int):
     _WS.clear()
 
 
-def workspace(device) -> torch.Tensor:
+def workspace(device, slot: int = 0) -> torch.Tensor:
     """One scratch slab per device, reused stream-ordered by every kernel.  Zero-filled once: its first 4 KiB are the
-    split-K arrival counters of the GEMM kernels, which every launch leaves at zero (include/ali_hip.h)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    split-K arrival counters of the GEMM kernels, which every launch leaves at zero (include/ali_hip.h).
+    ``slot`` > 0: the additional slabs the jobs of a multi-job GEMM launch use (one each: ``gemm_batch``)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), slot)
     ws = _WS.get(key)
     if ws is None or ws.numel() < _WS_BYTES:
         ws = torch.zeros(_WS_BYTES, dtype=torch.uint8, device=device)
@@ -295,6 +296,95 @@ def _launch(name, cost, fn):
     _PROFILE.records.append((name, cost[0], cost[1], (e0, e1), cost[2]))
 
 
+PAIR_GEMMS = True          # tests / A-B measurements: False = ``gemm_batch`` launches every GEMM on its own, at once
+_GEMM_BATCH = None
+GEMM_BATCH_SLOTS = 4
+
+
+class gemm_batch:
+    """``with ops.gemm_batch():`` -- the ``conv_fwd`` / ``conv_bwd_data`` calls made inside are RECORDED (include/ali_hip.h:
+    AliGemmJob) and issued together when the block ends: one launch per kernel variant instead of one per call.  The
+    calls of one block must be mutually independent and nothing inside the block may read a result of one of them
+    (``chain.run_parallel`` advances independent layer chains one GEMM at a time under such a block).  Each recorded
+    job works in a workspace slab of its own.  Launches of a kind no multi-job kernel exists for go out at once."""
+
+    def __init__(self):
+        self.jobs, self.keep, self.after = [], [], []
+        self.flops = self.bytes = 0.0
+
+    def __enter__(self):
+        global _GEMM_BATCH
+        self.prev, _GEMM_BATCH = _GEMM_BATCH, (self if PAIR_GEMMS else None)
+        return self
+
+    def __exit__(self, *exc):
+        global _GEMM_BATCH
+        _GEMM_BATCH = self.prev
+        if exc[0] is None:
+            self.flush()
+
+    def flush(self):
+        if self.jobs:
+            n = len(self.jobs)
+            arr = (_lib.AliGemmJob * n)(*self.jobs)
+
+            def go():
+                _lib.check(_lib.load().ali_gemm_launch_multi(n, arr, _stream()), "ali_gemm_launch_multi")
+            _launch("gconv", (self.flops, self.bytes, _NO_SHAPE), go)
+        todo = self.after
+        self.jobs, self.keep, self.after, self.flops, self.bytes = [], [], [], 0.0, 0.0
+        for fn in todo:
+            fn()
+
+
+def _gemm(which, name, g, a, w_packed, out, ep, in_ld, out_ld, live):
+    """one forward (which = 0) / data-gradient (1) GEMM: launched, or recorded into the open ``gemm_batch``"""
+    lib = _lib.load()
+    ep.in_ld, ep.out_ld = in_ld, out_ld
+    _f16_operands(g, which, a, w_packed, out, ep)
+    _set_tile_order(g, which, ep, a.device)
+    cost = _geom_cost(g, live)
+    kind = "fwd" if which == 0 else "bwd_data"
+    hook = _HOOK
+    b = _GEMM_BATCH
+    if b is not None and len(b.jobs) >= GEMM_BATCH_SLOTS:
+        b.flush()
+    if b is None:
+        ws = workspace(a.device)
+        fn = lib.ali_conv_fwd if which == 0 else lib.ali_conv_bwd_data
+
+        def go():
+            _lib.check(fn(byref(g), _view_ptr(a, in_ld, "a"), _chk(w_packed, "w"), _view_ptr(out, out_ld, "out"),
+                          byref(ep), c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_" + kind)
+        _launch(name, cost, go)
+        if hook is not None:
+            hook.gemm(kind, g, a, w_packed, out, ep, in_ld, out_ld)
+        return out
+    ws = workspace(a.device, 1 + len(b.jobs))
+    job = _lib.AliGemmJob()
+    fn = lib.ali_conv_fwd_job if which == 0 else lib.ali_conv_bwd_data_job
+    ev = None
+    if _PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _lib.check(fn(byref(g), _view_ptr(a, in_ld, "a"), _chk(w_packed, "w"), _view_ptr(out, out_ld, "out"), byref(ep),
+                  c_void_p(ws.data_ptr()), ws.numel(), byref(job), _stream()), "ali_conv_" + kind + "_job")
+    if job.opaque[0] == 1:
+        b.jobs.append(job)
+        b.keep.append((a, w_packed, out, ep, ws))
+        b.flops += cost[0]
+        b.bytes += cost[1]
+        if hook is not None:
+            b.after.append(lambda: hook.gemm(kind, g, a, w_packed, out, ep, in_ld, out_ld))
+    else:                               # a launch of another kind: it went out right away
+        if ev is not None:
+            ev[1].record()
+            _PROFILE.records.append((name, cost[0], cost[1], ev, cost[2]))
+        if hook is not None:
+            hook.gemm(kind, g, a, w_packed, out, ep, in_ld, out_ld)
+    return out
+
+
 def shadow16(t):
     """the fp16 twin a tensor carries (set by the fp16-MFMA launch that produced it, or by ``ensure_shadow16``)"""
     h = getattr(t, "_ali16", None)
@@ -390,37 +480,11 @@ def conv_fwd(g: AliConvGeom, x, w_packed, y, ep: AliEpilogue, in_ld=0, out_ld=0,
     """``in_ld`` / ``out_ld`` > 0: ``x`` / ``y`` are column ranges (strided views) of wider row-major buffers whose
     pixels are that many floats apart (AliEpilogue.in_ld / out_ld).  ``live`` = (channels of x, channels of y) that
     carry data when a stride is padded: accounting only (``_geom_cost``)."""
-    lib = _lib.load()
-    ws = workspace(x.device)
-    ep.in_ld, ep.out_ld = in_ld, out_ld
-    _f16_operands(g, 0, x, w_packed, y, ep)
-    _set_tile_order(g, 0, ep, x.device)
-
-    def go():
-        _lib.check(lib.ali_conv_fwd(byref(g), _view_ptr(x, in_ld, "x"), _chk(w_packed, "w"), _view_ptr(y, out_ld, "y"),
-                                    byref(ep),
-                                    c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_fwd")
-    _launch("gconv", _geom_cost(g, live), go)
-    if _HOOK is not None:
-        _HOOK.gemm("fwd", g, x, w_packed, y, ep, in_ld, out_ld)
-    return y
+    return _gemm(0, "gconv", g, x, w_packed, y, ep, in_ld, out_ld, live)
 
 
 def conv_bwd_data(g: AliConvGeom, dy, w_packed, dx, ep: AliEpilogue, in_ld=0, out_ld=0, live=None):
-    lib = _lib.load()
-    ws = workspace(dy.device)
-    ep.in_ld, ep.out_ld = in_ld, out_ld
-    _f16_operands(g, 1, dy, w_packed, dx, ep)
-    _set_tile_order(g, 1, ep, dy.device)
-
-    def go():
-        _lib.check(lib.ali_conv_bwd_data(byref(g), _view_ptr(dy, in_ld, "dy"), _chk(w_packed, "w"),
-                                         _view_ptr(dx, out_ld, "dx"), byref(ep),
-                                         c_void_p(ws.data_ptr()), ws.numel(), _stream()), "ali_conv_bwd_data")
-    _launch("gconv_t", _geom_cost(g, live), go)
-    if _HOOK is not None:
-        _HOOK.gemm("bwd_data", g, dy, w_packed, dx, ep, in_ld, out_ld)
-    return dx
+    return _gemm(1, "gconv_t", g, dy, w_packed, dx, ep, in_ld, out_ld, live)
 
 
 _PIXTAB = {}

@@ -27,7 +27,8 @@ from . import dp
 from . import dropout as _dropout
 from . import ops
 from . import chain as _chain
-from .chain import chain_backward, chain_forward, get_plan, slice_saved
+from .chain import (chain_backward, chain_backward_gen, chain_forward, chain_forward_gen, drive, get_plan,
+                    run_parallel, slice_saved)
 
 
 class FlatGroup:
@@ -292,12 +293,16 @@ class AliStepper:
             return None
         return torch.empty(B, ctot, dtype=torch.float32, device=device), mask
 
-    def _dx_forward(self, x0, n_log, save, groups=1, x_masked=False):
+    def _dx_forward_gen(self, x0, n_log, save, groups=1, x_masked=False):
         """D.dx, writing its end into the joint buffer when the chains can join: (dx_pre, join) for _d_forward"""
         join = self._join_begin(x0.shape[0], x0.device)
-        dx_pre = chain_forward(self.pDx, x0, True, n_log, save, groups,
-                               join=None if join is None else (join[0], 0, join[1]), first_mask_applied=x_masked)
+        dx_pre = yield from chain_forward_gen(self.pDx, x0, True, n_log, save, groups,
+                                              join=None if join is None else (join[0], 0, join[1]),
+                                              first_mask_applied=x_masked)
         return dx_pre, join
+
+    def _dx_forward(self, *args, **kwargs):
+        return drive(self._dx_forward_gen(*args, **kwargs))
 
     def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None, join=None, x_masked=False):
         B = x0.shape[0]
@@ -336,14 +341,20 @@ class AliStepper:
                                    need_params, dst, fold=fold, **self._join_in())
         gjoint = gjoint.reshape(B, -1)
         gx0 = gz = None
+        gens = []
         if need_params or need_x:
-            gx0, _ = chain_backward(self.pDx, s_dx, *self._branch_grad(gjoint, 0, B, 0, n_dx), n_log,
-                                    need_x, need_params, dst, gx_planes=planes if need_x else None, fold=fold,
-                                    **self._join_out(gjoint))
+            gens.append(chain_backward_gen(self.pDx, s_dx, *self._branch_grad(gjoint, 0, B, 0, n_dx), n_log,
+                                           need_x, need_params, dst, gx_planes=planes if need_x else None, fold=fold,
+                                           **self._join_out(gjoint)))
         if need_params or need_z:
             nz = gjoint.shape[1] - n_dx
-            gz, _ = chain_backward(self.pDz, s_dz, *self._branch_grad(gjoint, 0, B, n_dx, nz), nz, need_z,
-                                   need_params, dst, fold=fold, **self._join_out(gjoint))
+            gens.append(chain_backward_gen(self.pDz, s_dz, *self._branch_grad(gjoint, 0, B, n_dx, nz), nz, need_z,
+                                           need_params, dst, fold=fold, **self._join_out(gjoint)))
+        res = run_parallel(*gens)          # the two branches are independent: their GEMMs go out pairwise
+        if need_params or need_x:
+            gx0 = res[0][0]
+        if need_params or need_z:
+            gz = res[-1][0]
         if fold is not None:
             fold.flush()          # one launch sums the slabs of all of D's weight gradients
         return gx0, gz
@@ -377,9 +388,10 @@ class AliStepper:
         fam, images, idx, cont, onehots, zin, B = (self.family, cx["images"], cx["idx"], cx["cont"], cx["onehots"],
                                                    cx["zin"], cx["B"])
         x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
-        ex, sE = chain_forward(self.pE, x0e, True, n_log, True)
         gin, g_log = self._g_input(zin, onehots, cont)
-        gz, sG = chain_forward(self.pG, gin, True, g_log, True)
+        # E(x) and G(z) are independent chains: layer pairs share a launch (chain.run_parallel)
+        (ex, sE), (gz, sG) = run_parallel(chain_forward_gen(self.pE, x0e, True, n_log, True),
+                                          chain_forward_gen(self.pG, gin, True, g_log, True))
         # D(x, E(x)) and D(G(z), z) share the weights: one batch of 2B samples (reference order: real pass first)
         logits, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(images, ex.reshape(zin.shape), gz, zin, idx, cont, True)
         # (bce(D_valid, 0) + bce(D_fake, 1)) / 2 and its gradient for both halves: one launch
@@ -390,22 +402,32 @@ class AliStepper:
                                    **self._join_in())
         gjoint = gjoint.reshape(2 * B, -1)
         dst = self.opt_eg.grad_views
-        # ... real pass: only the z-side path (dxz -> dz) reaches E
         nz = gjoint.shape[1] - n_dx
-        g_ex, _ = chain_backward(self.pDz, slice_saved(s_dz, 0, 2), *self._branch_grad(gjoint, 0, B, n_dx, nz),
-                                 nz, True, False, **self._join_out(gjoint))
-        # of E's input gradient only the embedding planes are consumed (their tables are parameters of E)
         if self._fold is not None:
             self._fold.expect(_chain.wgrad_geoms(self.pE, sE) + _chain.wgrad_geoms(self.pG, sG))
-        g_x0e, _ = chain_backward(self.pE, sE, g_ex.reshape(ex.shape), n_log, bool(self._emb_planes), True, dst,
-                                  gx_planes=self._emb_planes or None, fold=self._fold)
-        if self._emb_planes:
-            self._plane_grads(g_x0e, idx, fam.e_tables, dst)
-        # ... fake pass: only the image path (dxz -> dx) reaches G
-        g_x0f, _ = chain_backward(self.pDx, slice_saved(s_dx, 1, 2), *self._branch_grad(gjoint, B, B, 0, n_dx),
-                                  n_log, True, False, gx_planes=(0,), **self._join_out(gjoint))
-        g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
-        g_gin, _ = chain_backward(self.pG, sG, g_gz, g_log, True, True, dst, fold=self._fold)
+
+        def real_branch():
+            # ... real pass: only the z-side path (dxz -> dz) reaches E
+            g_ex, _ = yield from chain_backward_gen(self.pDz, slice_saved(s_dz, 0, 2),
+                                                    *self._branch_grad(gjoint, 0, B, n_dx, nz), nz, True, False,
+                                                    **self._join_out(gjoint))
+            # of E's input gradient only the embedding planes are consumed (their tables are parameters of E)
+            g_x0e, _ = yield from chain_backward_gen(self.pE, sE, g_ex.reshape(ex.shape), n_log, bool(self._emb_planes),
+                                                     True, dst, gx_planes=self._emb_planes or None, fold=self._fold)
+            if self._emb_planes:
+                self._plane_grads(g_x0e, idx, fam.e_tables, dst)
+
+        def fake_branch():
+            # ... fake pass: only the image path (dxz -> dx) reaches G
+            g_x0f, _ = yield from chain_backward_gen(self.pDx, slice_saved(s_dx, 1, 2),
+                                                     *self._branch_grad(gjoint, B, B, 0, n_dx), n_log, True, False,
+                                                     gx_planes=(0,), **self._join_out(gjoint))
+            g_gz = g_x0f[..., 0].contiguous().reshape(gz.shape)
+            g, _ = yield from chain_backward_gen(self.pG, sG, g_gz, g_log, True, True, dst, fold=self._fold)
+            return g
+
+        # the two branches are independent from here on: their GEMMs go out pairwise
+        _, g_gin = run_parallel(real_branch(), fake_branch())
         if self._fold is not None:
             self._fold.flush()    # one launch sums the slabs of all of E's and G's weight gradients
         g_gin = g_gin.reshape(B, -1)
@@ -454,12 +476,25 @@ class AliStepper:
         cx["x0d"], cx["n_log"] = x0d, n_log
         cx["dx_pre"] = self._dx_forward(x0d, n_log, True, x_masked=masked)
 
+    def _d_real_all(self, cx):
+        """The whole D-real phase on one GPU: nothing has to hide an all-reduce, so E'(x) and D.dx(x) -- independent
+        chains -- run side by side (chain.run_parallel) instead of one in front of the E+G optimiser step."""
+        fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
+        x0d, n_log, masked = self._d_planes(images, idx, cont)
+        cx["x0d"], cx["n_log"] = x0d, n_log
+        x0e, _ = self._planes(images, idx, cont, fam.e_tables)
+        cx["dx_pre"], (cx["ex_pre"], _) = run_parallel(self._dx_forward_gen(x0d, n_log, True, x_masked=masked),
+                                                       chain_forward_gen(self.pE, x0e, True, n_log, False))
+        self._d_real_rest(cx)
+
     def _d_real_rest(self, cx):
         """D gradients on (x, E'(x)) (reference mnist.py:232-235); E' forward only."""
         fam, images, idx, cont = self.family, cx["images"], cx["idx"], cx["cont"]
         x0d, n_log = cx["x0d"], cx["n_log"]
-        x0e, _ = self._planes(images, idx, cont, fam.e_tables)
-        ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
+        ex = cx.pop("ex_pre", None)
+        if ex is None:
+            x0e, _ = self._planes(images, idx, cont, fam.e_tables)
+            ex, _ = chain_forward(self.pE, x0e, True, n_log, False)
         dx_pre, join = cx.pop("dx_pre")
         d_valid, sD = self._d_forward(x0d, n_log, ex, True, dx_pre=dx_pre, join=join)
         l, gl = ops.bce_logits(d_valid, 1.0, self.loss_scale)
@@ -502,7 +537,14 @@ class AliStepper:
         the collective's own stream -- right after the step; a step with ``wait`` first makes the compute stream wait
         for the all-reduce in flight.  The steps without ``wait`` that follow a reduce overlap with it."""
         segs = []
-        if do_eg:
+        if not (self.dist or self.segmented):
+            # one GPU, no collectives to hide: E'(x) runs beside D.dx(x), behind the E+G optimiser step
+            if do_eg:
+                segs.append((lambda cx: self._eg_grads(cx), self.opt_eg, False))
+                segs.append((lambda cx: (self._apply_eg(), self._d_real_all(cx)), self.opt_d, True))
+            else:
+                segs.append((lambda cx: self._d_real_all(cx), self.opt_d, False))
+        elif do_eg:
             segs.append((lambda cx: self._eg_grads(cx), self.opt_eg, False))
             segs.append((lambda cx: self._d_real_pre(cx), None, False))
             segs.append((lambda cx: (self._apply_eg(), self._d_real_rest(cx)), self.opt_d, True))

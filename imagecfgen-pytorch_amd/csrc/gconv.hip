@@ -112,8 +112,11 @@ constexpr int LDH = 40;      // fp16 LDS rows: 32 halves + 8 pad = 80 B (16-B al
 // F16 == 2: both operands are read from fp16 copies in memory (AliEpilogue.in16 / w16: the shadow the producing launch
 // left through out16, the fp16 twin of the packed weights): 16-byte gathers carry 8 k-values, a k-tile is 64 deep and
 // occupies exactly the fp32 tile's LDS image (128-B rows + 16 B pad), no conversion work, half the bytes through L2.
+// The kernel's body.  (bx_, by_, bz_) = the block's 3-D index in a plain launch; u_ = its linear index in a 1-D
+// ("lin1d": tail-split / cost-ordered) launch.  A job of a multi-job launch (gconv_multi_kernel) passes the same values,
+// decoded from its share of that launch's 1-D grid.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int F16 = 0>
-__global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
+__device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const int by_, const int bz_, const int u_) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;  // 16-byte gathers per thread per k-tile
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   // take one whole tile each (multiples of the CU count: every CU the same number) and whose remaining blocks share
   // the left-over tiles tail_split ways along K -- so the left-over costs every CU 1/tail_split of a tile instead of
   // costing a few CUs a whole one while the rest idle.
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nsplit = d.splitk;
+  int bx = bx_, by = by_, bz = bz_, nsplit = d.splitk;
   if (d.lin1d) {
-    int u = blockIdx.x;
+    int u = u_;
     bz = 0;
     nsplit = 1;
     if (u >= d.tail_u0) {
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
     // ================= generic path (first layers: channel stride not a multiple of 32) =================
     const int Ktot = ntaps * Cin;
     const int nkt = (Ktot + BK - 1) / BK;
-    const int kt_begin = blockIdx.z * d.kt_per_split;
+    const int kt_begin = bz * d.kt_per_split;
     const int kt_end = min(nkt, kt_begin + d.kt_per_split);
     const float* wptr[BP];
     bool bvalid[BP];
@@ -923,6 +926,32 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   else run_epilogue(F_{}, F_{}, BN0{}, false, d.out);
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int F16 = 0>
+__global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
+  gconv_body<BM, BN, WAVES_M, WAVES_N, MODE, F16>(d, blockIdx.x, blockIdx.y, blockIdx.z, blockIdx.x);
+}
+
+// Several independent GEMM launches of the same kernel variant in ONE launch (ali_gemm_launch_multi): the Encoder and the
+// Generator of an ALI iteration (mnist.py:224-226), the two branches of its backward pass, the dz / dx stacks of the
+// Discriminator are independent chains, so their layers go out pairwise -- half the launch boundaries, and the small
+// tail GEMMs (M <= 1024: 512 x 512 x 512 at 22 TF/s alone on 64-256 CUs) run beside a large layer's blocks instead of
+// alone.  Jobs are laid out one after the other in a 1-D grid, longest k-loop first; every job keeps its own workspace
+// (split-K slabs and arrival counters), epilogue and dispatch-order table.
+constexpr int kGJobs = 4;
+struct GJobs { int n, pad_; int blk0[kGJobs]; int gx[kGJobs], gy[kGJobs]; GDesc j[kGJobs]; };
+static_assert(sizeof(GJobs) <= 4000, "kernel argument segment");
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int F16 = 0>
+__global__ __launch_bounds__(256, 2) void gconv_multi_kernel(const GJobs jobs) {
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < jobs.n; ++i)
+    if ((int)blockIdx.x >= jobs.blk0[i]) k = i;
+  const int u = blockIdx.x - jobs.blk0[k];
+  const int gx = jobs.gx[k], gy = jobs.gy[k];
+  const int t2 = u / gx;
+  gconv_body<BM, BN, WAVES_M, WAVES_N, MODE, F16>(jobs.j[k], u - t2 * gx, t2 % gy, t2 / gy, u);
+}
+
 struct TileCfg { int bm, bn; };
 
 // fp32 MFMA cannot overlap with VALU work of the same SIMD, and a lone wave per SIMD cannot hide its barrier / memory
@@ -997,7 +1026,18 @@ static bool tile_costs(const GDesc& d, int bm, std::vector<int>& cost) {
   return true;
 }
 
-static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec, bool dense_k) {
+// A recorded launch (AliGemmJob): everything finalize_and_launch decided, for ali_gemm_launch_multi
+struct GJobRec {
+  uint64_t state;          // 1 = recorded
+  int variant;             // 0: <64,64,..,MODE 2> fp32, 1: <128,32,..,MODE 2> fp32 (the variants a multi-job kernel exists for)
+  int gx, gy, gz;          // its own grid
+  int cost;                // k-tiles per block (order of the jobs inside a combined launch)
+  GDesc d;
+};
+static_assert(sizeof(GJobRec) <= sizeof(AliGemmJob), "AliGemmJob too small");
+
+static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t stream, bool vec, bool dense_k,
+                               AliGemmJob* job = nullptr) {
   TileCfg tc;
   int max_taps = 0;
   const int tiles = plan_tiles(d, vec, tc, max_taps);
@@ -1104,6 +1144,17 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   const bool f16 = d.f16 && uni;
   const bool op16 = f16 && d.in16 && d.w16 && (d.Cin % 64) == 0;
   if (!f16) d.out16 = nullptr;      // only the fp16 kernels write the shadow
+  if (job && uni && !f16 && ((tc.bm == 64 && tc.bn == 64) || (tc.bm == 128 && tc.bn == 32))) {
+    GJobRec r;
+    memset(&r, 0, sizeof(r));
+    r.state = 1;
+    r.variant = tc.bm == 64 ? 0 : 1;
+    r.gx = (int)grid.x; r.gy = (int)grid.y; r.gz = (int)grid.z;
+    r.cost = (max_nkt + S - 1) / S;
+    r.d = d;
+    memcpy(job, &r, sizeof(r));
+    return ALI_OK;
+  }
 #define LAUNCH(BM_, BN_, WMM, WNN)                                                                    \
   do {                                                                                                  \
     if (op16) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 2, 2>), grid, block, 0, stream, d);  \
@@ -1439,8 +1490,8 @@ extern "C" int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which) {
   return (cin % BK) == 0 ? 1 : 0;
 }
 
-extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
-                            void* ws, size_t ws_bytes, ali_stream_t stream) {
+static int conv_fwd_impl(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
+                         void* ws, size_t ws_bytes, ali_stream_t stream, AliGemmJob* job) {
   if (!geom_ok(g) || !x || !w || !y) { set_error("ali_conv_fwd: bad argument"); return ALI_ERR_BAD_ARG; }
   if (conv_first_ok(g, nullptr, ep && ep->mfma_f16)) {
     // (the slot count ali_conv_mtiles reports depends on the geometry alone: an epilogue the per-image kernel cannot
@@ -1460,16 +1511,82 @@ extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w
   d.in = x; d.w = w; d.out = y;
   fill_epilogue(d, ep);
   setup_fwd(g, d);
-  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->C % 4) == 0, g->pad == 0);
+  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->C % 4) == 0, g->pad == 0, job);
 }
 
-extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w, float* dx,
-                                 const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream) {
+static int conv_bwd_data_impl(const AliConvGeom* g, const float* dy, const float* w, float* dx, const AliEpilogue* ep,
+                              void* ws, size_t ws_bytes, ali_stream_t stream, AliGemmJob* job) {
   if (!geom_ok(g) || !dy || !w || !dx) { set_error("ali_conv_bwd_data: bad argument"); return ALI_ERR_BAD_ARG; }
   GDesc d;
   memset(&d, 0, sizeof(d));
   d.in = dy; d.w = w; d.out = dx;
   fill_epilogue(d, ep);
   if (!setup_bwd_data(g, d)) return ALI_ERR_BAD_ARG;
-  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->K % 4) == 0, false);
+  return finalize_and_launch(d, ws, ws_bytes, (hipStream_t)stream, (g->K % 4) == 0, false, job);
+}
+
+extern "C" int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
+                            void* ws, size_t ws_bytes, ali_stream_t stream) {
+  return conv_fwd_impl(g, x, w, y, ep, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w, float* dx,
+                                 const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream) {
+  return conv_bwd_data_impl(g, dy, w, dx, ep, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int ali_conv_fwd_job(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
+                                void* ws, size_t ws_bytes, AliGemmJob* job, ali_stream_t stream) {
+  if (!job) { set_error("ali_conv_fwd_job: job is NULL"); return ALI_ERR_BAD_ARG; }
+  job->opaque[0] = 0;
+  return conv_fwd_impl(g, x, w, y, ep, ws, ws_bytes, stream, job);
+}
+extern "C" int ali_conv_bwd_data_job(const AliConvGeom* g, const float* dy, const float* w, float* dx,
+                                     const AliEpilogue* ep, void* ws, size_t ws_bytes, AliGemmJob* job,
+                                     ali_stream_t stream) {
+  if (!job) { set_error("ali_conv_bwd_data_job: job is NULL"); return ALI_ERR_BAD_ARG; }
+  job->opaque[0] = 0;
+  return conv_bwd_data_impl(g, dy, w, dx, ep, ws, ws_bytes, stream, job);
+}
+
+extern "C" int ali_gemm_launch_multi(int32_t n, const AliGemmJob* jobs, ali_stream_t stream_) {
+  if (n < 0 || (n > 0 && !jobs)) { set_error("ali_gemm_launch_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<GJobRec> rec[2];
+  for (int i = 0; i < n; ++i) {
+    GJobRec r;
+    memcpy(&r, &jobs[i], sizeof(r));
+    if (r.state != 1 || r.variant < 0 || r.variant > 1) { set_error("ali_gemm_launch_multi: job %d was not recorded", i); return ALI_ERR_BAD_ARG; }
+    rec[r.variant].push_back(r);
+  }
+  for (int v = 0; v < 2; ++v) {
+    std::vector<GJobRec>& all = rec[v];
+    // longest blocks first (the dispatcher hands blocks out in order: the short ones fill the tail)
+    std::stable_sort(all.begin(), all.end(), [](const GJobRec& a, const GJobRec& b) { return a.cost > b.cost; });
+    for (size_t j0 = 0; j0 < all.size(); j0 += kGJobs) {
+      const size_t cnt = std::min(all.size() - j0, (size_t)kGJobs);
+      if (cnt == 1) {
+        const GJobRec& r = all[j0];
+        dim3 grid(r.gx, r.gy, r.gz);
+        if (v == 0) hipLaunchKernelGGL((gconv_kernel<64, 64, 2, 2, 2>), grid, dim3(256), 0, stream, r.d);
+        else hipLaunchKernelGGL((gconv_kernel<128, 32, 4, 1, 2>), grid, dim3(256), 0, stream, r.d);
+      } else {
+        GJobs gj;
+        memset(&gj, 0, sizeof(gj));
+        long long blocks = 0;
+        for (size_t i = 0; i < cnt; ++i) {
+          const GJobRec& r = all[j0 + i];
+          gj.j[i] = r.d;
+          gj.gx[i] = r.gx; gj.gy[i] = r.gy;
+          gj.blk0[i] = (int)blocks;
+          blocks += (long long)r.gx * r.gy * r.gz;
+        }
+        gj.n = (int)cnt;
+        if (blocks > (1LL << 30)) { set_error("ali_gemm_launch_multi: grid too large"); return ALI_ERR_BAD_ARG; }
+        if (v == 0) hipLaunchKernelGGL((gconv_multi_kernel<64, 64, 2, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, gj);
+        else hipLaunchKernelGGL((gconv_multi_kernel<128, 32, 4, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, gj);
+      }
+      int rc = check_launch("gconv_multi_kernel");
+      if (rc) return rc;
+    }
+  }
+  return ALI_OK;
 }

@@ -190,6 +190,23 @@ int ali_conv_bwd_weight(const AliConvGeom* g, const float* x, const float* dy, f
                         int32_t split_target /* with job: blocks this GEMM should have inside the combined launch
                                                 (clamped to 256..1024; 0 = 1024, the stand-alone rule) */,
                         void* ws, size_t ws_bytes, ali_stream_t stream);
+/* Independent forward / data-gradient GEMMs in ONE launch.  ali_conv_fwd_job / ali_conv_bwd_data_job take the arguments
+ * of ali_conv_fwd / ali_conv_bwd_data and, when the launch is of a kind a multi-job kernel exists for (fp32, uniform-tap
+ * loop, 64x64 or 128x32 tiles), record it in *job (opaque[0] = 1) instead of launching; any other launch is issued on
+ * `stream` right away (opaque[0] = 0), exactly as the plain entry point would.  ali_gemm_launch_multi then issues the
+ * recorded jobs: up to 4 of the same kernel variant per launch, longest k-loops first.  The jobs of one call must be
+ * mutually independent (no job reads what another writes), each must have been given a workspace of its own (split-K
+ * slabs and arrival counters live there), and every operand named at record time must still be alive and unchanged.
+ * mnist.py:224-248: E(x) and G(z), the two branches of the E+G backward pass, D.dx and D.dz are such chains. */
+typedef struct AliGemmJob {
+  uint64_t opaque[112];
+} AliGemmJob;
+int ali_conv_fwd_job(const AliConvGeom* g, const float* x, const float* w_kxc, float* y, const AliEpilogue* ep,
+                     void* ws, size_t ws_bytes, AliGemmJob* job, ali_stream_t stream);
+int ali_conv_bwd_data_job(const AliConvGeom* g, const float* dy, const float* w_cxk, float* dx, const AliEpilogue* ep,
+                          void* ws, size_t ws_bytes, AliGemmJob* job, ali_stream_t stream);
+int ali_gemm_launch_multi(int32_t n, const AliGemmJob* jobs, ali_stream_t stream);
+
 /* Launches deferred weight-gradient GEMMs (jobs[i].opaque[0] == 1 each) together, 12 per launch, longest blocks first.
  * Every operand and workspace region named at ali_conv_bwd_weight time must still be alive and unchanged. */
 int ali_wgrad_launch_multi(int32_t n, const AliWgradJob* jobs, ali_stream_t stream);

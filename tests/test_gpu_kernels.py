@@ -442,6 +442,57 @@ def test_deferred_weight_gradients_match_their_own_launches():
         assert torch.equal(dw, dwr) and torch.equal(db, dbr)
 
 
+def test_multi_job_gemm_launch_equals_single_launches():
+    """ops.gemm_batch / ali_gemm_launch_multi: independent forward and data-gradient GEMMs recorded (AliGemmJob) and
+    issued as ONE launch per kernel variant == the same GEMMs launched one by one, bit for bit -- incl. a split-K job
+    (own slabs and arrival counters per job), a cost-ordered / tail-split job, a 128x32-tile job (narrow output: its own
+    variant), fused epilogues, and a first-layer launch that no multi-job kernel serves (goes out at once)."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(31)
+
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, device="cuda", generator=g) * scale
+
+    cases = []   # (which, geom, a, w, out shape, epilogue factory)
+    # split-K 1x1 GEMM (M = 512 rows), the dz / dxz tail of mnist.py:98-105,127-136
+    cases.append((0, ops.geom(512, 1, 1, 512, 1, 1, 512, 1, 1, 1, 0), rnd(512, 1, 1, 512), rnd(512, 1, 512, scale=0.05),
+                  (512, 1, 1, 512), lambda: ops.epilogue(bias=bias512, act=ops.ACT_LEAKY, slope=0.2)))
+    # a conv layer with padding: cost-ordered dispatch (+ tail split at this size)
+    cases.append((0, ops.geom(512, 13, 13, 128, 7, 7, 256, 3, 3, 2, 1), rnd(512, 13, 13, 128), rnd(256, 9, 128, scale=0.03),
+                  (512, 7, 7, 256), lambda: ops.epilogue(act=ops.ACT_LEAKY, slope=0.1)))
+    # first layer (8-channel stride): no multi-job kernel -> launched at once, still correct
+    cases.append((0, ops.geom(64, 28, 28, 8, 14, 14, 64, 3, 3, 2, 1), rnd(64, 28, 28, 8), rnd(64, 9, 8, scale=0.1),
+                  (64, 14, 14, 64), lambda: ops.epilogue()))
+    # transposed conv forward (data-gradient GEMM, 4 sub-pixel phases) with a mask epilogue
+    cases.append((1, ops.geom(512, 7, 7, 256, 3, 3, 512, 3, 3, 2, 0), rnd(512, 3, 3, 512), rnd(256, 9, 512, scale=0.02),
+                  (512, 7, 7, 256), lambda: ops.epilogue(mask=mask256)))
+    # narrow output (32 channels): the 128x32-tile variant
+    cases.append((1, ops.geom(512, 24, 24, 32, 11, 11, 64, 4, 4, 2, 0), rnd(512, 11, 11, 64), rnd(32, 16, 64, scale=0.05),
+                  (512, 24, 24, 32), lambda: ops.epilogue()))
+    bias512 = rnd(512)
+    mask256 = (torch.rand(512, 256, device="cuda", generator=g) > 0.2).float() * 1.25
+
+    def run(which, geom, a, w, shape, ep):
+        out = torch.full(shape, float("nan"), device="cuda")
+        (ops.conv_fwd if which == 0 else ops.conv_bwd_data)(geom, a, w, out, ep())
+        return out
+
+    refs = [run(*c) for c in cases]
+    with ops.gemm_batch() as batch:
+        outs = [run(*c) for c in cases]
+        assert len(batch.jobs) == 4                       # four recorded, the first-layer launch (case 2) went out directly
+        assert all(torch.isnan(o).all() for i, o in enumerate(outs) if i != 2) and not torch.isnan(outs[2]).any()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert not torch.isnan(o).any() and torch.equal(o, r), f"job {i}"
+    # again, back to back with other inputs: slabs / counters of the jobs' workspaces are left clean
+    for c in cases:
+        c[2].mul_(-0.5)
+    refs = [run(*c) for c in cases]
+    with ops.gemm_batch():
+        outs = [run(*c) for c in cases]
+    assert all(torch.equal(o, r) for o, r in zip(outs, refs))
+
+
 @pytest.mark.parametrize("B,C,ld", [(512, 1024, 1024), (70, 36, 40), (1030, 512, 512)])
 def test_discriminator_head_gemv(B, C, ld):
     """ali_head_fwd / ali_head_wgrad: Conv2d(C, 1, 1) on a 1x1 map (mnist.py:127) as a GEMV and its weight / bias gradient."""

@@ -440,42 +440,47 @@ def test_stepper_three_iterations_free_running():
             assert abs(rp[k].item() - ro[k]) <= 1e-3 * max(1.0, abs(ro[k])), (i, k, rp[k].item(), ro[k])
 
 
-@pytest.mark.parametrize("variant", ["no_join", "own_launches"])
+@pytest.mark.parametrize("variant", ["no_join", "own_launches", "no_pairing", "no_pairing_bs512"])
 def test_scheduling_variants_of_the_stepper_agree(variant):
     """The launch-saving schedules are pure re-arrangements: (a) D's joint rows written in place by the branch ends
     (no cat / mask pass / slice copies / act' passes) vs the plain three-chain schedule -- bit-identical losses, scores
     and weights; (b) weight gradients issued as one multi-job launch per pass vs one launch per layer -- identical up to
     the summation order of the pixel split (1e-6 of the losses, weights within a sign-flip of rounding-level Adam
-    steps)."""
+    steps); (c) independent chains (E || G, the two branches of the E+G backward pass, D.dx || D.dz backward, E' || D.dx)
+    advanced in lock step with their GEMMs issued as multi-job launches (chain.run_parallel / ali_gemm_launch_multi)
+    vs every GEMM launched on its own -- bit-identical (every job keeps its own tile, split-K and workspace)."""
     import ali_hip
     from ali_hip import ops
+    bs = 512 if variant.endswith("bs512") else 64
+    exact = variant in ("no_join", "no_pairing", "no_pairing_bs512")
     ali_hip.manual_seed(5)
-    _, (E1, G1, D1), a, batches = _stepper_setup(capture=False, bs=64)
+    _, (E1, G1, D1), a, batches = _stepper_setup(capture=False, bs=bs)
     ali_hip.manual_seed(5)
-    _, (E2, G2, D2), b, _ = _stepper_setup(capture=False, bs=64)
+    _, (E2, G2, D2), b, _ = _stepper_setup(capture=False, bs=bs)
     assert a._join and a._fold is not None
     if variant == "no_join":
         b._join = False
-    old = ops.DEFER_WGRAD_LAUNCH
+    old, old_pair = ops.DEFER_WGRAD_LAUNCH, ops.PAIR_GEMMS
     outs = []
     try:
         for images, c, z in batches:
-            ops.DEFER_WGRAD_LAUNCH = True
+            ops.DEFER_WGRAD_LAUNCH, ops.PAIR_GEMMS = True, True
             r1 = {k: v.item() for k, v in a.step(images.cuda(), to_dev(c), z.cuda()).items()}
             ops.DEFER_WGRAD_LAUNCH = variant != "own_launches"
+            ops.PAIR_GEMMS = not variant.startswith("no_pairing")
             r2 = {k: v.item() for k, v in b.step(images.cuda(), to_dev(c), z.cuda()).items()}
             outs.append((r1, r2))
     finally:
-        ops.DEFER_WGRAD_LAUNCH = old
+        ops.DEFER_WGRAD_LAUNCH, ops.PAIR_GEMMS = old, old_pair
     for i, (r1, r2) in enumerate(outs):
         for k in r1:
-            if variant == "no_join":
+            if exact:
                 assert r1[k] == r2[k], (i, k, r1[k], r2[k])
             else:   # first iteration: same weights, only the summation order differs; later: sign-like Adam steps of
                 # rounding-level gradients have diverged (same bound as the free-running test against the oracle)
                 tol = 2e-5 if i == 0 else 1e-3
                 assert abs(r1[k] - r2[k]) <= tol * max(1.0, abs(r1[k])), (i, k, r1[k], r2[k])
-    if variant == "no_join":
+    if exact:
         assert torch.equal(a.opt_d.flat, b.opt_d.flat) and torch.equal(a.opt_eg.flat, b.opt_eg.flat)
     else:
         steps = len(batches) * 2
