@@ -30,6 +30,7 @@ struct Tuning {
   int tile_m_scale;                         // ALI_TILE_M_SCALE=n: choose the gconv / wgrad tiles as if the batch were n
                                             // times larger (tests: a small batch runs the tiles of the bench batch)
   int wbm, wbn;                             // ALI_WBM / ALI_WBN: force the weight-gradient tile (one of its variants)
+  int no_t1_mfma;                           // ALI_NO_T1_MFMA=1: the VALU gather forms of the direct one-channel kernels (A/B)
 };
 inline Tuning read_tuning() {
   {
@@ -42,6 +43,7 @@ inline Tuning read_tuning() {
     v.no_first_wgrad = (int)num("ALI_NO_FIRST_WGRAD");
     v.tile_m_scale = (int)num("ALI_TILE_M_SCALE");
     v.wbm = (int)num("ALI_WBM"); v.wbn = (int)num("ALI_WBN");
+    v.no_t1_mfma = (int)num("ALI_NO_T1_MFMA");
     return v;
   }
 }

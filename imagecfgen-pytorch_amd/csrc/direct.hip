@@ -12,6 +12,7 @@
 // They run on the VALU with the operands staged in LDS; algorithmically they are HBM bound
 // (fwd/dgrad move the C-channel map once: 4*C bytes per pixel for 2*C*R*S flops).
 #include "ali_common.h"
+#include <algorithm>
 
 namespace ali {
 
@@ -49,8 +50,22 @@ __global__ __launch_bounds__(256) void tconv1_fwd_kernel(const T1Desc d) {
   constexpr int PR = T1F_RB + R_ - 1, PC = T1F_CB + S_ - 1;   // staged patch of big pixels
   float* patch = smem;                                      // [PR*PC][T1F_LDP]
   const int t = threadIdx.x;
-  const int b = blockIdx.z;
-  const int h0 = blockIdx.y * T1F_RB, w0 = blockIdx.x * T1F_CB;
+  // Block -> (image, row band, column block).  Neighbouring row bands share R-1 rows of the big map: dispatched in the
+  // natural order (band fastest) they land on eight different XCDs and every L2 fetches the shared rows again (1.65x
+  // the map's bytes from HBM).  The dispatcher deals blocks round-robin over the XCDs (MI355X_MICROARCH.md: blocks b and
+  // b + 8 share one), so the j-th block an XCD receives takes band j % bands of image (j / bands) * 8 + xcd: the bands
+  // of an image run back to back on ONE L2.  (Speed only: any placement computes the same thing.)
+  int b = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
+  if ((gridDim.z & 7) == 0) {
+    const int per = gridDim.x * gridDim.y;
+    const int lin = bx + gridDim.x * (by + gridDim.y * b);
+    const int xcd = lin & 7, j = lin >> 3;
+    const int il = j / per, rem = j - il * per;
+    b = il * 8 + xcd;
+    by = rem / gridDim.x;
+    bx = rem - by * gridDim.x;
+  }
+  const int h0 = by * T1F_RB, w0 = bx * T1F_CB;
   // patch origin in the big map: row = h0 + pad - (R-1), col = w0 + pad - (S-1)
   const int pr0 = h0 + d.pad - (R_ - 1), pc0 = w0 + d.pad - (S_ - 1);
   const int k4 = t & 7, grp = t >> 3;                       // 32 groups = T1F_RB rows x 8 runs of 4 pixels
@@ -108,6 +123,105 @@ __global__ __launch_bounds__(256) void tconv1_fwd_kernel(const T1Desc d) {
       if (h < d.H && wq < d.W)
         d.out[((long long)(b * d.H + h) * d.W + wq) * d.ostride] = apply_act(acc[px] + bias, d.act, d.slope) * rs;
     }
+  }
+}
+
+// ---------------------------------------------------------------- forward, scatter form on the matrix cores
+// The gather form above re-reads the big map (R + RB - 1) / RB times and waits for memory twice per block: 1.1-1.8 TB/s.
+// Scatter form: the contribution of input pixel p to the output through tap t is contrib[p][t] = sum_k big[p][k] * w[t][k]
+// -- a [P*Q x K] x [K x taps] product with every row of the big map read exactly ONCE, straight from memory into MFMA
+// operand registers (v_mfma_f32_16x16x4_f32: 16 pixels x 16 taps per tile, exact fp32).  One block owns one image: its
+// contributions stay in LDS ([P*Q][LDC], 42-58 KB), and after a barrier every output pixel sums its <= R*S taps in a
+// fixed order, adds the bias, applies the activation.  HBM traffic = the map once + the 1-channel output.
+//   A (16 x 4 per MFMA): lane l holds pixel m = l % 16, k-slot l / 16; one 16-byte load gives a lane channels
+//     16 j + 4 (l / 16) + e, e = 0..3 -- the k-slots of four MFMA steps (the weights use the same permutation);
+//   B: lane l holds tap n = l % 16 of the same k-slot; all K/4 values per tap tile sit in registers for the whole block;
+//   D: lane l holds tap n = l % 16 of pixels 4 (l / 16) + i, i = 0..3.
+// NT = 16-tap tiles (1: up to 16 taps, 2: up to 32), KC = K / 16 (2 or 4).
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+template <int NT, int KC, int NW>
+__global__ __launch_bounds__(64 * NW) void tconv1_fwd_mfma_kernel(const T1Desc d, int LDC) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* contrib = smem;                                  // [P*Q][LDC]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x;
+  const int PQ = d.P * d.Q, T = d.R * d.S, K = d.K;
+  const int m = lane & 15, kq = lane >> 4;
+  // weights: wreg[nt][j][e] = w[tap = 16 nt + m][channel 16 j + 4 kq + e]   (taps >= T: 0)
+  float wreg[NT][KC][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tap = nt * 16 + m;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if (tap < T) v = *reinterpret_cast<const f32x4v*>(d.w + (long long)tap * K + 16 * j + 4 * kq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wreg[nt][j][e] = v[e];
+    }
+  }
+  const float* src = d.big + (long long)b * PQ * K + 4 * kq;
+  const int ntile = (PQ + 15) >> 4;
+  auto load_tile = [&](int tile, f32x4v (&a)[KC]) {
+    const int pix = tile * 16 + m;
+    const bool ok = tile < ntile && pix < PQ;
+    const float* p = src + (long long)(ok ? pix : 0) * K;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      a[j] = *reinterpret_cast<const f32x4v*>(p + 16 * j);
+      if (!ok) a[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto compute_tile = [&](int tile, const f32x4v (&a)[KC]) {
+    f32x4v acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][e], wreg[nt][j][e], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int tap = nt * 16 + m;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pix = tile * 16 + 4 * kq + i;
+        if (tap < T && pix < PQ) contrib[pix * LDC + tap] = acc[nt][i];
+      }
+    }
+  };
+  // tiles wave, wave + NW, ...: three tiles of loads in flight per wave (3 x K x 64 B = 12 KB at K = 64)
+  f32x4v a0[KC], a1[KC], a2[KC];
+  load_tile(wave, a0);
+  load_tile(wave + NW, a1);
+  load_tile(wave + 2 * NW, a2);
+  for (int tile = wave; tile < ntile; tile += 3 * NW) {
+    compute_tile(tile, a0);
+    load_tile(tile + 3 * NW, a0);
+    if (tile + NW < ntile) compute_tile(tile + NW, a1);
+    load_tile(tile + 4 * NW, a1);
+    if (tile + 2 * NW < ntile) compute_tile(tile + 2 * NW, a2);
+    load_tile(tile + 5 * NW, a2);
+  }
+  __syncthreads();
+  const float bias = d.bias ? d.bias[0] : 0.f;
+  const float rs = d.rowscale ? d.rowscale[(long long)b * d.rowscale_ld] : 1.f;
+  float* outb = d.out + (long long)b * d.H * d.W * d.ostride;
+  for (int o = t; o < d.H * d.W; o += 64 * NW) {
+    const int oh = o / d.W, ow = o - oh * d.W;
+    float v = 0.f;
+    for (int r = 0; r < d.R; ++r) {
+      const int ih = oh + d.pad - r;
+      if ((unsigned)ih >= (unsigned)d.P) continue;
+      for (int sx = 0; sx < d.S; ++sx) {
+        const int iw = ow + d.pad - sx;
+        if ((unsigned)iw < (unsigned)d.Q) v += contrib[(ih * d.Q + iw) * LDC + r * d.S + sx];
+      }
+    }
+    outb[(long long)o * d.ostride] = apply_act(v + bias, d.act, d.slope) * rs;
   }
 }
 
@@ -295,6 +409,100 @@ __global__ __launch_bounds__(256) void tconv1_wgrad_rb_kernel(const T1Desc d, in
   }
 }
 
+// ---------------------------------------------------------------- weight gradient on the matrix cores (K = 64, one small channel)
+// dw[k][tap] = sum over pixels of big[pix][k] * small[pix + tap] is a [K x pixels] x [pixels x taps] product: per step of
+// 4 pixels one v_mfma_f32_16x16x4_f32 per group of 16 channels.  The VALU kernels above are LDS-latency bound (1.3 TB/s
+// of the big map); here a lane's ONE 16-byte load per step -- big[pix0 + l/16][4 (l%16) .. +3] -- is its A operand for
+// the four channel groups {4 m + e} (e = 0..3), the 1-channel map sits zero-padded in LDS and gives the B operand with
+// one ds_read_b32 (tap n = l % 16 of pixel pix0 + l/16), eight steps of loads are in flight per wave.  A block walks
+// over images, keeps its sums in registers, folds its waves through LDS in a fixed order and leaves one slab.
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void tconv1_wgrad_mfma_kernel(const T1Desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int K = 64;
+  const int SH = d.P + d.R - 1, SW = d.Q + d.S - 1;      // zero-padded small image: entry (i, j) = small[i - pad][j - pad]
+  float* simg = smem;                                     // [SH][SW]
+  float* red = smem + ((SH * SW + 3) & ~3);               // [NW][4][NT][64][4] fold scratch
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int PQ = d.P * d.Q, T = d.R * d.S;
+  int toff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tap = nt * 16 + m;
+    const int tp = tap < T ? tap : 0;
+    toff[nt] = (tp / d.S) * SW + (tp % d.S);
+  }
+  f32x4v acc[4][NT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[e][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const float rQ = 1.0f / (float)d.Q;
+  const int nstep = (PQ + 3) >> 2;
+  constexpr int DEPTH = 8;
+  for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = t; i < SH * SW; i += 64 * NW) {
+      const int sr = i / SW, sc = i - sr * SW;
+      const int ih = sr - d.pad, iw = sc - d.pad;
+      float v = 0.f;
+      if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+        v = d.small[((long long)(b * d.H + ih) * d.W + iw) * d.sstride];
+      simg[i] = v;
+    }
+    __syncthreads();
+    const float* src = d.big + (long long)b * PQ * K + 4 * m;
+    auto load_step = [&](int st) -> f32x4v {
+      const int pix = st * 4 + kq;
+      if (st < nstep && pix < PQ) return *reinterpret_cast<const f32x4v*>(src + (long long)pix * K);
+      return f32x4v{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4v a[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) a[u] = load_step(wave + u * NW);
+    for (int st0 = wave; st0 < nstep; st0 += DEPTH * NW) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int st = st0 + u * NW;
+        const f32x4v av = a[u];
+        a[u] = load_step(st + DEPTH * NW);
+        if (st < nstep) {
+          int pix = st * 4 + kq;
+          if (pix >= PQ) pix = PQ - 1;                       // (its A values are zero)
+          int p = (int)((float)pix * rQ);
+          int q = pix - p * d.Q;
+          if (q < 0) { --p; q += d.Q; } else if (q >= d.Q) { ++p; q -= d.Q; }
+          const float* sp = simg + p * SW + q;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float bv = sp[toff[nt]];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[e][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv, acc[e][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // fold the waves in a fixed order: acc[e][nt][i] = dw[channel 4 * (4 kq + i) + e][tap 16 nt + m]
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      *reinterpret_cast<f32x4v*>(red + (((wave * 4 + e) * NT + nt) * 64 + lane) * 4) = acc[e][nt];
+  __syncthreads();
+  float* part = d.part + (long long)blockIdx.x * (K * T);
+  for (int o = t; o < 4 * NT * 64 * 4; o += 64 * NW) {
+    const int i = o & 3, l = (o >> 2) & 63, nt = (o >> 8) % NT, e = (o >> 8) / NT;
+    float v = 0.f;
+    for (int w = 0; w < NW; ++w) v += red[(((w * 4 + e) * NT + nt) * 64 + l) * 4 + i];
+    const int ch = 4 * (4 * (l >> 4) + i) + e, tap = nt * 16 + (l & 15);
+    if (tap < T) part[ch * T + tap] = v;
+  }
+}
+
 // out[c*s_c + k*s_k + tap*s_tap] = sum_b part[b][(c*K + k)*T + tap]   (one wave per output, fixed order)
 __global__ void t1_reduce_kernel(const float* __restrict__ part, int nblk, int K, int T, int NC, float* __restrict__ out,
                                  long long s_k, long long s_tap, long long s_c) {
@@ -336,6 +544,21 @@ extern "C" int ali_tconv1_fwd(const float* big, const float* w_tk, const float* 
   d.ostride = ostride; d.act = act; d.slope = slope;
   d.rowscale = rowscale; d.rowscale_ld = rowscale_ld;
   if ((K % T1F_KC) != 0 || R != S) { set_error("ali_tconv1_fwd: needs K %% 32 == 0 and a square kernel"); return ALI_ERR_BAD_ARG; }
+  {
+    // scatter form on the matrix cores: one block per image, its tap contributions in LDS (maps up to ~32 x 32)
+    const int T = R * S;
+    const int LDC = (T <= 16 ? 17 : T) | 1;               // odd pitch: the gather's pixel-strided reads spread over the banks
+    const size_t lds_sc = (size_t)P * Q * LDC * sizeof(float);
+    if ((K == 32 || K == 64) && T <= 32 && lds_sc <= 64 * 1024 && tuning().no_t1_mfma == 0) {
+#define T1M(NT_, KC_) hipLaunchKernelGGL((tconv1_fwd_mfma_kernel<NT_, KC_, 8>), dim3(B), dim3(512), lds_sc, (hipStream_t)stream, d, LDC)
+      if (T <= 16 && K == 64) T1M(1, 4);
+      else if (T <= 16) T1M(1, 2);
+      else if (K == 64) T1M(2, 4);
+      else T1M(2, 2);
+#undef T1M
+      return check_launch("tconv1_fwd_mfma_kernel");
+    }
+  }
   const size_t lds = (size_t)(T1F_RB + R - 1) * (T1F_CB + S - 1) * T1F_LDP * sizeof(float);
   dim3 grid((W + T1F_CB - 1) / T1F_CB, (H + T1F_RB - 1) / T1F_RB, B);
 #define T1F(T_, S__) hipLaunchKernelGGL((tconv1_fwd_kernel<T_, S__>), grid, dim3(256), lds, (hipStream_t)stream, d)
@@ -360,7 +583,7 @@ extern "C" int ali_tconv1_dgrad(const float* small, int32_t sstride, const float
   d.B = B; d.P = P; d.Q = Q; d.K = K; d.H = H; d.W = W; d.R = R; d.S = S; d.pad = pad;
   const long long total = (long long)B * P * Q * (K / 4);
   long long nb = (total + 255) / 256;
-  if (nb > 4096) nb = 4096;
+  if (nb > 4096) nb = 4096;              // (one output per thread was measured slower: 75 vs 54 us, the tap preload dominates)
   if (256 % (K / 4) != 0) { set_error("ali_tconv1_dgrad: K/4 must divide 256"); return ALI_ERR_BAD_ARG; }
   const int T = R * S;
 #define T1D(T_) hipLaunchKernelGGL(tconv1_dgrad_kernel<T_>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, d)
@@ -393,7 +616,7 @@ extern "C" int ali_tconv1_wgrad(const float* big, const float* small, int32_t ss
   }
   const int bands = (P + T1W_RB - 1) / T1W_RB;
   const int nitems = bands * B;
-  const int nblk = nitems < 2 * kNumCU ? nitems : 2 * kNumCU;
+  const int nblk = nitems < 8 * kNumCU ? nitems : 8 * kNumCU;   // (latency bound: as many resident blocks as LDS lets in)
   if (!ws || ws_bytes < (size_t)nblk * nc * K * T * sizeof(float)) { set_error("ali_tconv1_wgrad: workspace too small"); return ALI_ERR_WORKSPACE; }
   T1Desc d = {};
   d.big = big; d.small = small; d.sstride = sstride; d.part = reinterpret_cast<float*>(ws);
@@ -403,6 +626,18 @@ extern "C" int ali_tconv1_wgrad(const float* big, const float* small, int32_t ss
   const int SWp = (Q4 + S - 1 + 3) & ~3;
   const size_t lds_rb = ((size_t)T1W_RB * Q4 * K + (size_t)nc * (T1W_RB + R - 1) * SWp) * sizeof(float);
   const bool rb = (256 / K) >= R && S <= 5 && S >= 3 && lds_rb <= 64 * 1024 && (nc == 1 || nc == 5 || nc == 7);
+  constexpr int MW = 8;                                   // waves per block of the matrix-core form
+  const int mnt = (T + 15) / 16;
+  const size_t lds_m = ((size_t)(((P + R - 1) * (Q + S - 1) + 3) & ~3) + (size_t)MW * 4 * mnt * 64 * 4) * sizeof(float);
+  if (nc == 1 && K == 64 && T <= 32 && lds_m <= 64 * 1024 && tuning().no_t1_mfma == 0 &&
+      ws_bytes >= (size_t)std::min(B, 2 * kNumCU) * K * T * sizeof(float)) {
+    const int nb = std::min(B, 2 * kNumCU);
+    if (mnt == 1) hipLaunchKernelGGL((tconv1_wgrad_mfma_kernel<1, MW>), dim3(nb), dim3(64 * MW), lds_m, st, d);
+    else hipLaunchKernelGGL((tconv1_wgrad_mfma_kernel<2, MW>), dim3(nb), dim3(64 * MW), lds_m, st, d);
+    hipLaunchKernelGGL(t1_reduce_kernel, dim3(K * T), dim3(64), 0, st, d.part, nb, K, T, 1, dw, (long long)s_k,
+                       (long long)s_tap, (long long)s_c);
+    return check_launch("tconv1_wgrad_mfma");
+  }
   if (rb) {
 #define WRB(NC_, S_) hipLaunchKernelGGL((tconv1_wgrad_rb_kernel<NC_, S_>), dim3(nblk), dim3(256), lds_rb, st, d, nitems, bands)
     if (nc == 1 && S == 3) WRB(1, 3); else if (nc == 1 && S == 4) WRB(1, 4); else if (nc == 1) WRB(1, 5);
