@@ -308,10 +308,17 @@ def abort_batch_counts():
     _NBT["pending"] = None
 
 
-def flush_batch_counts():
+def flush_batch_counts(extra=()):
+    """apply the collected num_batches_tracked increments (+ ``extra`` = [(int64 counter tensor, increment), ...]) in
+    one launch"""
     pend, _NBT["pending"] = _NBT["pending"], None
-    if pend:
-        torch._foreach_add_([e[0] for e in pend.values()], [e[1] for e in pend.values()])
+    jobs = [(e[0], e[1]) for e in (pend or {}).values()] + list(extra)
+    cuda = [(t, k) for t, k in jobs if t.is_cuda]
+    for t, k in jobs:
+        if not t.is_cuda:
+            t += k
+    if cuda:
+        ops.add_i64_multi([t.reshape(1) if t.dim() == 0 else t for t, _ in cuda], [k for _, k in cuda])
 
 
 class _Saved:

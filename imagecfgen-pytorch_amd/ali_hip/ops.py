@@ -1009,14 +1009,32 @@ def g_input_table_grad(onehot, g, off, out):
     return out
 
 
-def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0):
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0, arrive=None):
+    """``arrive`` (zeroed int32 device tensor): ``dev_step`` counts COMPLETED steps and the launch advances it itself
+    (include/ali_hip.h: ali_adam)."""
     lib = _lib.load()
-    ds = None
+    ds = ar = None
     if dev_step is not None:
         assert dev_step.is_cuda and dev_step.dtype == torch.int32
         ds = c_void_p(dev_step.data_ptr())
+    if arrive is not None:
+        assert arrive.is_cuda and arrive.dtype == torch.int32 and dev_step is not None
+        ar = c_void_p(arrive.data_ptr())
     _lib.check(lib.ali_adam(_chk(p, "p"), _chk(g, "g"), _chk(m, "m"), _chk(v, "v"), p.numel(), lr, beta1, beta2, eps,
-                            step, ds, grad_scale, _stream()), "ali_adam")
+                            step, ds, ar, grad_scale, _stream()), "ali_adam")
+
+
+def add_i64_multi(counters, incs):
+    """counters[i] += incs[i] for int64 device scalars, one launch (include/ali_hip.h: ali_add_i64_multi)"""
+    n = len(counters)
+    if n == 0:
+        return
+    for t in counters:
+        if not (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+            raise ValueError("add_i64_multi: need one-element int64 CUDA tensors")
+    ptrs = (c_void_p * n)(*[t.data_ptr() for t in counters])
+    inc = (ctypes.c_int64 * n)(*[int(v) for v in incs])
+    _lib.check(_lib.load().ali_add_i64_multi(n, ptrs, inc, _stream()), "ali_add_i64_multi")
 
 
 def assemble_planes(X, idx, tables, cont, B, H, W, Cpad, out=None, mask=None):

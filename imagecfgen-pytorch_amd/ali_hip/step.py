@@ -71,7 +71,8 @@ class FlatGroup:
                 off += k
         self.lr, self.betas, self.eps = lr, betas, eps
         self.steps = 0
-        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph replays)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side count of completed steps (graph replays)
+        self.arrive = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
 
     @staticmethod
     def logical(views):
@@ -90,9 +91,9 @@ class FlatGroup:
 
     def adam(self, grad_scale=1.0):
         self.steps += 1
-        self.step_t += 1
+        # the kernel runs step step_t + 1 and its last block advances step_t: no launch for the counter
         ops.adam(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.steps,
-                 dev_step=self.step_t, grad_scale=grad_scale)
+                 dev_step=self.step_t, grad_scale=grad_scale, arrive=self.arrive)
 
     # torch.optim-like surface for callers that keep the returned optimisers
     def zero_grad(self):
@@ -326,7 +327,9 @@ class AliStepper:
         per pass, in the order a, b (chain_forward groups / dropout.paired_passes)."""
         with _dropout.paired_passes(self._n_drop):
             x0, n_log, masked = self._d_planes_pair(Xa, Xb, idx, cont)
-            logit, saved = self._d_forward(x0, n_log, torch.cat([zina, zinb], dim=0), save, 2, x_masked=masked)
+            zin2 = torch.empty((2 * zina.shape[0],) + tuple(zina.shape[1:]), dtype=zina.dtype, device=zina.device)
+            ops.copy_multi([(zin2[:zina.shape[0]], zina), (zin2[zina.shape[0]:], zinb)])
+            logit, saved = self._d_forward(x0, n_log, zin2, save, 2, x_masked=masked)
         return logit, saved
 
     def _d_backward(self, saved, glogit, need_params, need_x, need_z, planes=None):
@@ -374,7 +377,8 @@ class AliStepper:
     # ------------------------------------------------------------------ the iteration, phase by phase
     def _begin(self, images, c, z, do_eg=True):
         B = images.shape[0]
-        self.iter_t += 1
+        # (iter_t = iterations completed so far: it keys this iteration's Dropout2d masks and advances at the end of the
+        # iteration, in the launch that also applies the BatchNorm batch counts)
         if self._fold is not None:
             self._fold.abandon()       # (nothing is pending after a completed iteration)
         _dropout.begin_iteration(self.iter_t, owner=self, tag=(B, bool(do_eg)))
@@ -526,7 +530,8 @@ class AliStepper:
         s3 = ops.bce_logits_pair(logits, cx["B"], 0.0, 0.0, 1.0, want_grad=False)[0]
         cx["out"]["dg"], cx["out"]["de"] = s3[1], s3[2]
         _dropout.end_iteration()
-        _chain.flush_batch_counts()        # all BatchNorm num_batches_tracked increments of the iteration: one launch
+        # all BatchNorm num_batches_tracked increments of the iteration and the iteration counter: one launch
+        _chain.flush_batch_counts(extra=[(self.iter_t, 1)])
         if self.dist and average_bn:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
             dp.average_buffers_(self.bn_buffers, self.pg)

@@ -710,12 +710,15 @@ __global__ void bce_logits_kernel(const float* __restrict__ logit, int B, float 
   }
 }
 
+// `arrive` != null: dev_step holds the number of COMPLETED steps; this launch is step dev_step[0] + 1 and its last block
+// stores that back (every block has read dev_step before it arrives: no block can see the new value) -- the device-side
+// step count of a captured graph advances without a launch of its own.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                            int step_host, const int* __restrict__ dev_step, float grad_scale) {
+                            int step_host, int* __restrict__ dev_step, int* __restrict__ arrive, float grad_scale) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
-  const int t = dev_step ? dev_step[0] : step_host;
+  const int t = dev_step ? __hip_atomic_load(dev_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (arrive ? 1 : 0) : step_host;
   const float bc1 = (float)(1.0 - pow((double)b1, (double)t));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
   const float step_size = lr / bc1;
@@ -729,6 +732,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
   }
+  if (arrive) {
+    __syncthreads();                   // (every thread of the block has computed with t)
+    if (threadIdx.x == 0) {
+      const int a = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a == (int)gridDim.x - 1) {
+        __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dev_step, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// several int64 counters += their increments in one launch (num_batches_tracked of every BatchNorm2d, the iteration counter)
+constexpr int kAddJobs = 16;
+struct AddJobs { int n; long long* ptr[kAddJobs]; long long inc[kAddJobs]; };
+__global__ void add_i64_multi_kernel(const AddJobs jobs) {
+  const int i = threadIdx.x;
+  if (i < jobs.n) jobs.ptr[i][0] += jobs.inc[i];
 }
 
 
@@ -1370,11 +1391,31 @@ extern "C" int ali_bce_logits_pair(const float* logit, int32_t B, float target_a
 }
 
 extern "C" int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                        float eps, int32_t step, const int32_t* dev_step, float grad_scale, ali_stream_t stream) {
-  if (!p || !g || !m || !v || n <= 0 || (!dev_step && step < 1)) { set_error("ali_adam: bad argument"); return ALI_ERR_BAD_ARG; }
+                        float eps, int32_t step, int32_t* dev_step, int32_t* arrive, float grad_scale, ali_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || (!dev_step && step < 1) || (arrive && !dev_step)) {
+    set_error("ali_adam: bad argument");
+    return ALI_ERR_BAD_ARG;
+  }
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 4)), dim3(kEwBlock), 0, ST(stream), p, g, m, v, (long long)n, lr, beta1, beta2,
-                     eps, (int)step, reinterpret_cast<const int*>(dev_step), grad_scale);
+                     eps, (int)step, reinterpret_cast<int*>(dev_step), reinterpret_cast<int*>(arrive), grad_scale);
   return check_launch("adam_kernel");
+}
+
+extern "C" int ali_add_i64_multi(int32_t n, int64_t* const* ptrs, const int64_t* incs, ali_stream_t stream) {
+  if (n < 0 || (n > 0 && (!ptrs || !incs))) { set_error("ali_add_i64_multi: bad argument"); return ALI_ERR_BAD_ARG; }
+  for (int j0 = 0; j0 < n; j0 += kAddJobs) {
+    AddJobs aj;
+    memset(&aj, 0, sizeof(aj));
+    for (int i = j0; i < n && i < j0 + kAddJobs; ++i) {
+      if (!ptrs[i]) { set_error("ali_add_i64_multi: null counter %d", i); return ALI_ERR_BAD_ARG; }
+      aj.ptr[aj.n] = reinterpret_cast<long long*>(ptrs[i]);
+      aj.inc[aj.n++] = incs[i];
+    }
+    hipLaunchKernelGGL(add_i64_multi_kernel, dim3(1), dim3(64), 0, ST(stream), aj);
+    int rc = check_launch("add_i64_multi_kernel");
+    if (rc) return rc;
+  }
+  return ALI_OK;
 }
 
 extern "C" int ali_assemble_planes(const float* X, const int32_t* idx, const float* const* emb_tables, int32_t n_emb,

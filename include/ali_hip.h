@@ -326,9 +326,15 @@ int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, fl
 
 /* torch.optim.Adam step (mnist.py:176-179,230,236,241), no amsgrad / decay.
  * One launch over a flat parameter segment.  The 1-based step count is `step`, or *dev_step when
- * dev_step != NULL (graph replays); the gradient is read as grad_scale * g (1/world for DP). */
+ * dev_step != NULL (graph replays); the gradient is read as grad_scale * g (1/world for DP).
+ * With `arrive` (a zeroed device int32 the launch leaves at zero; needs dev_step): *dev_step is the number of COMPLETED
+ * steps -- the launch runs step *dev_step + 1 and its last block stores that value back, so a captured graph's step
+ * count advances without a launch of its own. */
 int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-             float eps, int32_t step, const int32_t* dev_step, float grad_scale, ali_stream_t stream);
+             float eps, int32_t step, int32_t* dev_step, int32_t* arrive, float grad_scale, ali_stream_t stream);
+/* counters[i][0] += incs[i] for n device int64 counters in one launch (nn.BatchNorm2d.num_batches_tracked of every
+ * layer, mnist.py:111-123 forward in train mode; the stepper's iteration counter). */
+int ali_add_i64_multi(int32_t n, int64_t* const* counters, const int64_t* incs, ali_stream_t stream);
 
 /* BCEWithLogitsLoss of two passes batched along the rows, rows [0,B) against target_a and [B,2B) against target_b
  * (mnist.py:228: (bce(D_valid, 0) + bce(D_fake, 1)) / 2; :245-248: the two sigmoid().mean() scores):

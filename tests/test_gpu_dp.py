@@ -106,6 +106,7 @@ def _emulate(world, iters):
     for r in range(world):
         st, D, data = _replica(r, None, False)
         st.world = world                     # 1/world is folded into the Adam kernel; no process group: no collectives
+        st.segmented = True                  # ... but the data-parallel schedule (segments cut where the all-reduces go)
         reps.append((st, D, data, _DropoutState()))
     outs = None
     with torch.no_grad():
