@@ -418,6 +418,14 @@ def run_parallel(*gens):
     return res
 
 
+def delayed(gen, rounds: int):
+    """``gen`` entering ``run_parallel`` ``rounds`` rounds late (pairs a short chain's GEMMs with later, larger layers of
+    its partner instead of with the partner's first one)"""
+    for _ in range(rounds):
+        yield
+    return (yield from gen)
+
+
 def chain_forward(*args, **kwargs):
     """``chain_forward_gen`` run on its own: returns (y_last, saved list)."""
     return drive(chain_forward_gen(*args, **kwargs))
@@ -429,7 +437,7 @@ def chain_backward(*args, **kwargs):
 
 
 def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool, groups: int = 1,
-                      join=None, first_mask_applied: bool = False):
+                      join=None, first_mask_applied: bool = False, lane=None):
     """Generator form of the forward pass (see ``run_parallel``): yields after every GEMM request.
     x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list).
 
@@ -438,6 +446,7 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
     concatenation and the Dropout2d in front of the consuming chain cost no launch (mnist.py:152-154).
     ``first_mask_applied``: the input already carries the first stage's Dropout2d mask (it was folded into the
     producers that way); the mask is still drawn, in order, and saved for the backward pass.
+    ``lane`` (dropout.Lane): the chain's Dropout2d masks are the requests of that lane (chains advanced side by side).
 
     ``groups`` > 1: the batch holds that many independent forward passes back to back (equal sample counts).  The
     convolutions run once over all of them; BatchNorm takes its batch statistics -- and updates the running ones --
@@ -461,7 +470,7 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
             mask, early = early, None
         for kind, arg in st.pre:
             if kind == "drop" and training and mask is None:
-                mask = _dropout.next_mask(B, c_log, arg, cur.device, Cp)
+                mask = _dropout.next_mask(B, c_log, arg, cur.device, Cp, lane=lane)
             elif kind == "bn":
                 bn = arg
         sv = _Saved()
@@ -510,7 +519,7 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
         # of y, which the kept entries preserve and the dropped ones do not need (their gradient is masked to 0).
         if (training and nk == ["drop"] and st.act in (ACT_NONE, ACT_LEAKY) and st.kind in ("conv", "convT")
                 and not _is_tconv1(st, Cp)):
-            folded = _dropout.next_mask(B, out_shape[3], nxt.pre[0][1], cur.device, out_shape[3])
+            folded = _dropout.next_mask(B, out_shape[3], nxt.pre[0][1], cur.device, out_shape[3], lane=lane)
         # A BatchNorm behind this conv: its batch statistics are column sums of this stage's output -- accumulated
         # per M-tile by the GEMM epilogue (times the Dropout2d mask that may sit in between), no extra pass
         bn_fwd = None
@@ -518,7 +527,7 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
             nbn = [a for k, a in nxt.pre if k == "bn"][0]
             if training or nbn.running_mean is None:
                 if training and nk == ["drop", "bn"]:
-                    early = _dropout.next_mask(B, out_shape[3], nxt.pre[0][1], cur.device, out_shape[3])
+                    early = _dropout.next_mask(B, out_shape[3], nxt.pre[0][1], cur.device, out_shape[3], lane=lane)
                 slots, tile_rows, pixel_major = ops.conv_mtiles(g, 0)
                 rows_g = (B // groups) * (1 if pixel_major else out_shape[1] * out_shape[2])
                 if slots > 0 and (groups == 1 or (B % groups == 0 and rows_g % tile_rows == 0

@@ -88,6 +88,43 @@ def masks_consumed() -> int:
     return _state["pos"]
 
 
+class Lane:
+    """A sub-sequence of the iteration's mask requests that starts at a FIXED request index: lets two layer chains that
+    the reference runs one after the other (D.dx, then D.dz: mnist.py:152-153) be advanced side by side while each
+    still receives exactly the masks of its own turn.  ``next_mask(..., lane=lane)`` serves request ``lane.i`` and
+    advances the lane only; the caller moves the global position past both chains afterwards (``advance``)."""
+
+    def __init__(self, start):
+        self.i = int(start)
+
+
+def lanes_start(n_ahead: int):
+    """The request index the next ``next_mask`` call would serve, if the coming ``n_ahead`` requests can be looked up
+    by index (an injected tape, or the iteration's recorded mask plan); None otherwise (first iteration of a stepper:
+    masks are drawn one launch at a time, in order)."""
+    inj = _state["inject"]
+    if inj is not None:
+        i = _state["pos"]
+        return i if i + n_ahead - 1 + _state["pair"] < len(inj) else None
+    plan, rec = _state["plan"], _state["record"]
+    if plan is None or rec is not None:
+        return None
+    i = _state["req"]
+    return i if i + n_ahead <= len(plan["req"]) else None
+
+
+def advance(n: int):
+    """move the global position past ``n`` requests that were served through lanes"""
+    if _state["inject"] is not None:
+        _state["pos"] += n
+        return
+    plan = _state["plan"]
+    for i in range(_state["req"], _state["req"] + n):
+        B, C, _, _ = plan["req"][i]
+        _state["offset"] += B * C
+    _state["req"] += n
+
+
 def _pad(mask, cpad):
     if mask.shape[1] == cpad:
         return mask
@@ -122,9 +159,17 @@ def peek_mask(skip: int, B: int, C: int, p: float, device, cpad=None):
     return plan["buf"][lo:lo + B * cpad].view(B, cpad)
 
 
-def next_mask(B: int, C: int, p: float, device, cpad=None) -> torch.Tensor:
-    """[B, cpad] mask of the next Dropout2d: columns < C are Bernoulli(1-p)/(1-p), channel-padding columns are 1."""
+def next_mask(B: int, C: int, p: float, device, cpad=None, lane=None) -> torch.Tensor:
+    """[B, cpad] mask of the next Dropout2d: columns < C are Bernoulli(1-p)/(1-p), channel-padding columns are 1.
+    ``lane``: serve the lane's next request instead of the global one (see ``Lane``)."""
     cpad = C if cpad is None else cpad
+    if lane is not None:
+        base = _state["pos"] if _state["inject"] is not None else _state["req"]
+        m = peek_mask(lane.i - base, B, C, p, device, cpad)
+        if m is None:
+            raise RuntimeError(f"dropout lane: request {lane.i} is not a ({B}, {C}, p={p}) mask of this iteration's sequence")
+        lane.i += 1
+        return m
     inj = _state["inject"]
     if inj is not None:
         if _state["pos"] >= len(inj):

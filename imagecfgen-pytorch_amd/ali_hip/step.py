@@ -231,6 +231,7 @@ class AliStepper:
             self._fold.arena()
         self._join_act = (lx.act, lx.slope)
         self._join_skip = sum(1 for pl in (self.pDx, self.pDz) for st in pl.stages if any(k == "drop" for k, _ in st.pre))
+        self._n_drop_dx = sum(1 for st in self.pDx.stages if any(k == "drop" for k, _ in st.pre))
 
     # ------------------------------------------------------------------ pieces
     def _planes(self, X, idx, cont, tables, out=None, mask=None):
@@ -294,12 +295,14 @@ class AliStepper:
             return None
         return torch.empty(B, ctot, dtype=torch.float32, device=device), mask
 
-    def _dx_forward_gen(self, x0, n_log, save, groups=1, x_masked=False):
+    def _dx_forward_gen(self, x0, n_log, save, groups=1, x_masked=False, join=None, lane=None):
         """D.dx, writing its end into the joint buffer when the chains can join: (dx_pre, join) for _d_forward"""
-        join = self._join_begin(x0.shape[0], x0.device)
+        if join is None:                     # (False: the caller knows there is none)
+            join = self._join_begin(x0.shape[0], x0.device)
+        join = join or None
         dx_pre = yield from chain_forward_gen(self.pDx, x0, True, n_log, save, groups,
                                               join=None if join is None else (join[0], 0, join[1]),
-                                              first_mask_applied=x_masked)
+                                              first_mask_applied=x_masked, lane=lane)
         return dx_pre, join
 
     def _dx_forward(self, *args, **kwargs):
@@ -307,12 +310,36 @@ class AliStepper:
 
     def _d_forward(self, x0, n_log, zin, save, groups=1, dx_pre=None, join=None, x_masked=False):
         B = x0.shape[0]
-        if dx_pre is None:
-            dx_pre, join = self._dx_forward(x0, n_log, save, groups, x_masked)
-        dx, s_dx = dx_pre
-        n_dx = dx.shape[-1]
-        dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups,
-                                 join=None if join is None else (join[0], n_dx, join[1]))
+        # D.dx and D.dz are independent chains (mnist.py:152-153): advanced side by side, their GEMMs share launches.
+        # Each keeps the Dropout2d masks of its own turn in the reference's order (dropout.Lane) -- which needs the
+        # iteration's mask sequence to be known ahead (not in a stepper's very first iteration: then one after the other)
+        pair, lanes = dx_pre is None, (None, None)
+        if pair and self._join_skip:
+            base = _dropout.lanes_start(self._join_skip)
+            pair = base is not None
+            if pair:
+                lanes = (_dropout.Lane(base), _dropout.Lane(base + self._n_drop_dx))
+        if pair:
+            join = self._join_begin(B, x0.device)
+            n_dx = _chain._out_shape(self.pDx.stages[-1], B, 1, 1, 1)[3]
+            (dx_pre, _), (dz, s_dz) = run_parallel(
+                self._dx_forward_gen(x0, n_log, save, groups, x_masked, join=join if join is not None else False,
+                                     lane=lanes[0]),
+                # (one round late: D.dx's first conv runs on a kernel of its own, D.dz's two GEMMs ride with the next two)
+                _chain.delayed(chain_forward_gen(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups,
+                                                 join=None if join is None else (join[0], n_dx, join[1]), lane=lanes[1]),
+                               1))
+            if self._join_skip:
+                _dropout.advance(self._join_skip)
+            dx, s_dx = dx_pre
+            assert dx.shape[-1] == n_dx
+        else:
+            if dx_pre is None:
+                dx_pre, join = self._dx_forward(x0, n_log, save, groups, x_masked)
+            dx, s_dx = dx_pre
+            n_dx = dx.shape[-1]
+            dz, s_dz = chain_forward(self.pDz, zin.reshape(B, 1, 1, -1), True, zin.numel() // B, save, groups,
+                                     join=None if join is None else (join[0], n_dx, join[1]))
         if join is None:
             joint = torch.cat([dx.reshape(B, -1), dz.reshape(B, -1)], dim=1).reshape(B, 1, 1, -1)
             logit, s_dxz = chain_forward(self.pDxz, joint, True, joint.shape[-1], save, groups)

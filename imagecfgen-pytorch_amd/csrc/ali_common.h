@@ -30,6 +30,7 @@ struct Tuning {
   int tile_m_scale;                         // ALI_TILE_M_SCALE=n: choose the gconv / wgrad tiles as if the batch were n
                                             // times larger (tests: a small batch runs the tiles of the bench batch)
   int wbm, wbn;                             // ALI_WBM / ALI_WBN: force the weight-gradient tile (one of its variants)
+  int no_xcd;                               // ALI_NO_XCD=1: raster tile order on deep grids instead of XCD-contiguous chunks (A/B)
   int no_t1_mfma;                           // ALI_NO_T1_MFMA=1: the VALU gather forms of the direct one-channel kernels (A/B)
 };
 inline Tuning read_tuning() {
@@ -44,6 +45,7 @@ inline Tuning read_tuning() {
     v.tile_m_scale = (int)num("ALI_TILE_M_SCALE");
     v.wbm = (int)num("ALI_WBM"); v.wbn = (int)num("ALI_WBN");
     v.no_t1_mfma = (int)num("ALI_NO_T1_MFMA");
+    v.no_xcd = (int)num("ALI_NO_XCD");
     return v;
   }
 }

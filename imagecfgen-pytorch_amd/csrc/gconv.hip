@@ -76,6 +76,7 @@ struct GDesc {
   int nphase, splitk, kt_per_split;
   int ntile_m, ntile_n;     // m-tiles (all phases) and n-tiles of the launch
   int lin1d;                // 1-D grid: tail-split and/or cost-ordered launches, see the kernel's block-index decoding
+  int xcd_chunk;            // > 0 (1-D grid): XCD-contiguous tile order, blocks per XCD (see the decoding)
   int tail_u0, tail_split;  // whole tiles first, then the left-over tiles cut tail_split ways along K
   const int* order;         // AliEpilogue.tile_order (M-tile ids, longest k-loop first) or null
   int ldi;                  // pixel pitch of the gathered operand (floats): Cin, or AliEpilogue.in_ld
@@ -152,7 +153,19 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
       bz = r - (r / d.tail_split) * d.tail_split;
       nsplit = d.tail_split;
     }
-    if (d.order) {
+    if (d.xcd_chunk) {
+      // Deep grids of the large-map layers (spectrogram models: rows ordered (image, pixel)): neighbouring M-tiles are
+      // neighbouring output rows and share (R - stride) of their R input rows, the n-tiles of an M-tile share all of
+      // them.  The dispatcher deals consecutive blocks to DIFFERENT XCDs, so in raster order every L2 fetches those
+      // rows again (fp16 5x5 stride-2 layers: 60 % L2 hit rate, 3.9x the algorithmic bytes over the fabric at 4.2 TB/s --
+      // memory bound, profiles/r03_*esrf_f16*).  Here XCD x (blocks u = x mod 8; which blocks share an XCD is all that
+      // is assumed, and only for speed) walks the contiguous range [x * chunk, (x + 1) * chunk) of (M-tile, n-tile)
+      // pairs, n fastest: what its resident blocks gather overlaps, and stays in its L2.
+      const int id = (u & 7) * d.xcd_chunk + (u >> 3);
+      if (id >= d.ntile_m * d.ntile_n) return;
+      bx = id / d.ntile_n;
+      by = id - bx * d.ntile_n;
+    } else if (d.order) {
       // "Longest tile first" launches: dispatch slot u -> (rank in the cost-sorted M-tile list, n-tile), n fastest.
       // The dispatcher deals workgroups round-robin over the CUs (measured: CU c of an all-resident grid holds slots
       // c, c+256, c+512, ...), so every CU receives one tile of each cost quartile instead of e.g. four corner tiles.
@@ -1136,10 +1149,19 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     d.order = reinterpret_cast<const int*>(d.ep.tile_order);
   d.lin1d = (d.tail_split > 1 || d.order) ? 1 : 0;
   if (d.tail_split == 1) d.tail_u0 = (int)blocks;
+  // XCD-contiguous tile order for deep grids of (image, pixel)-ordered rows (see the kernel's decoding)
+  d.xcd_chunk = 0;
+  bool img_major = d.nphase >= 1;
+  for (int i = 0; i < d.nphase; ++i) img_major = img_major && !d.ph[i].pixmajor;
+  if (!d.lin1d && S == 1 && !job && img_major && blocks >= 8LL * kNumCU && blocks < (1LL << 30) && tuning().no_xcd == 0) {
+    d.xcd_chunk = (int)((blocks + 7) / 8);
+    d.lin1d = 1;
+  }
   d.ctr = reinterpret_cast<int*>(ws);
   d.ws = reinterpret_cast<float*>(ws_payload(ws));
   dim3 grid(tiles, ntile_n, S), block(256);
   if (d.lin1d) grid = dim3(d.tail_u0 + (int)(blocks - d.tail_u0) * d.tail_split, 1, 1);
+  if (d.xcd_chunk) grid = dim3(8 * d.xcd_chunk, 1, 1);
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
   const bool f16 = d.f16 && uni;
   const bool op16 = f16 && d.in16 && d.w16 && (d.Cin % 64) == 0;
