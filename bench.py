@@ -272,7 +272,7 @@ def main():
                 return None
             n = tot = 0.0
             for line in open(path):
-                if line.startswith("#") or kernel_substr not in line:
+                if line.startswith("#") or not any(k in line for k in kernel_substr):
                     continue
                 name, launches, fetch_kb, write_kb = line.rsplit(",", 3)
                 n += float(launches)
@@ -287,13 +287,13 @@ def main():
             f = fam[name]
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
             peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-            ksub = {"gconv": "gconv_kernel", "wgrad": "wgrad_fast"}
+            ksub = {"gconv": ("gconv_kernel", "gconv_multi_kernel", "conv_first_kernel"), "wgrad": ("wgrad_fast", "conv_first_wgrad")}
 
             def pair(k):      # algorithmic bytes next to the counters' traffic, per launch, for one kernel family
                 v = fam[k]
                 return {"alg_bytes_per_launch": round(v["bytes"] / v["launches"]), "traffic": pmc_traffic(ksub[k])}
 
-            traffic = pmc_traffic(ksub.get(name, name))
+            traffic = pmc_traffic(ksub.get(name, (name,)))
             roof = {"bound": "mfma", "kernel": {"gconv": "ali::gconv_kernel", "wgrad": "ali::wgrad_fast_kernel"}.get(name, name),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic,

@@ -15,4 +15,4 @@ for k in sorted(acc, key=lambda k: -max(acc[k].values())):
     n = max(cnt[k].values())
     if len(sys.argv) > 2 and n < int(sys.argv[2]):
         continue
-    print(k[-60:] + "," + str(n) + "," + ",".join(f"{acc[k][c] / max(cnt[k][c], 1):.4g}" for c in names))
+    print("\"" + k[-60:] + "\"," + str(n) + "," + ",".join(f"{acc[k][c] / max(cnt[k][c], 1):.4g}" for c in names))

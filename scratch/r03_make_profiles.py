@@ -18,7 +18,13 @@ def table(name):
     path = f"{src}/{name}_summary.csv"
     if not os.path.exists(path):
         return None
-    return {r["kernel"]: r for r in csv.DictReader(open(path))}
+    lines = [ln.rstrip("\n") for ln in open(path) if ln.strip()]
+    cols = lines[0].split(",")
+    out = {}
+    for ln in lines[1:]:                       # kernel names contain commas: split from the right
+        parts = ln.rsplit(",", len(cols) - 1)
+        out[parts[0].strip('"')] = dict(zip(cols, [parts[0].strip('"')] + parts[1:]))
+    return out
 
 
 f, wr = table("fetch"), table("write")
@@ -35,5 +41,10 @@ for name, hdr in (("tcc", "TCC_HIT_sum TCC_MISS_sum"), ("sq", "SQ_* (quad-cycles
     if os.path.exists(path):
         with open(f"profiles/r03_pmc_{name}_{tag}.csv", "w") as out:
             out.write(f"# rocprofv3 --kernel-trace --pmc {hdr} -- {cmd} --steps 3 --warmup 2 --no-graph; mean per launch\n")
-            out.write(open(path).read())
+            lines = [ln.rstrip("\n") for ln in open(path) if ln.strip()]
+            n = len(lines[0].split(","))
+            out.write(lines[0] + "\n")
+            for ln in lines[1:]:
+                parts = ln.rsplit(",", n - 1)
+                out.write("\"" + parts[0].strip('"') + "\"," + ",".join(parts[1:]) + "\n")
 print(sorted(x for x in os.listdir("profiles") if x.startswith("r03") and tag in x))
