@@ -977,7 +977,13 @@ static TileCfg pick_tile(long long M, int N, bool f16) {
   if (f16) {
     // the fp16 loop is bound by the bytes its blocks pull through L2 (a 32-cycle MFMA is 16x the fp32 rate; operands
     // are still fp32 in memory): 128x128 tiles halve them per FLOP -- measured 149 -> 290 TF/s on the 1024 -> 2048
-    // layer of the ESRF stacks -- as soon as they still give every other CU a block
+    // layer of the ESRF stacks -- as soon as they still give every other CU a block.
+    // Round 3, measured and rejected on the ESRF iteration (62.1 ms of GEMM time with this rule): a 256 x 256 tile with
+    // 8 waves (128 accumulator registers per lane leave room for one staged k-tile: 66.5 ms) or with 4 waves and the
+    // accumulators in AGPRs (one wave per SIMD hides nothing: 194 ms); three k-tiles of gathers in flight instead of
+    // two (62.5 ms: the loop is not waiting for global memory); XCD-contiguous tile order (kept, neutral).  Per k-tile
+    // a CU issues 64 ds_write_b128 (13 LDS cycles each) beside its 128 ds_read_b128: 1344 LDS cycles for 1024 MFMA
+    // cycles -- the register-staged LDS fill is the limit; the fix is LDS-DMA staging, not tile area.
     if (N > 64 && blocks(128, 128) >= kNumCU / 2) { best.bm = 128; best.bn = 128; return best; }
     if (N > 64 && blocks(64, 128) >= kNumCU / 2) { best.bm = 64; best.bn = 128; return best; }
     return best;
