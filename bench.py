@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
                     help="f16 = fp16-MFMA forward / data-gradient GEMMs with fp32 accumulation (BASELINE config 5: esrf)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pipeline-reduce", action="store_true",
+                    help="N > 1: overlap the last all-reduce of an iteration with the next iteration's E(x) / G(z) forward "
+                         "(AliStepper(pipeline_reduce=True); same arithmetic, tests/test_gpu_dp.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -160,11 +163,12 @@ def main():
     betas = (0.5, 0.999) if args.workload == "mnist" else (0.5, 0.9)
 
     if args.mode == "stepper":
-        stepper = AliStepper(E, G, D, betas=betas, process_group=pg, capture=not args.no_graph, precision=args.precision)
+        stepper = AliStepper(E, G, D, betas=betas, process_group=pg, capture=not args.no_graph, precision=args.precision,
+                             pipeline_reduce=args.pipeline_reduce and world > 1)
 
         def one(i):
             images, c, z = batches[i % len(batches)]
-            return stepper.step(images, c, z)
+            return stepper.step(images, c, z, ahead=batches[(i + 1) % len(batches)] if stepper.pipeline_reduce else None)
     else:
         assert world == 1, "autograd mode is single-GPU (reference schedule through torch.autograd)"
         oe = torch.optim.Adam(list(E.parameters()) + list(G.parameters()), lr=1e-4, betas=betas)
@@ -331,7 +335,8 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{names[args.workload]} synthetic, bs={bs}/GPU, {arith}, mode={args.mode}"
                                    f"{'' if args.no_graph or args.mode != 'stepper' else ('+hipgraph' if world == 1 else '+hipgraph-segments')}",
-                       "global_batch": bs * world, "parallelism": f"dp{world}"},
+                       "global_batch": bs * world,
+                       "parallelism": f"dp{world}" + ("+pipelined-allreduce" if args.pipeline_reduce and world > 1 else "")},
             "roofline": roof,
             "step_roofline": step_roof,
             "ms_per_step_ranks": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},

@@ -437,7 +437,7 @@ def chain_backward(*args, **kwargs):
 
 
 def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in: int, save: bool, groups: int = 1,
-                      join=None, first_mask_applied: bool = False, lane=None):
+                      join=None, first_mask_applied: bool = False, lane=None, alloc=None):
     """Generator form of the forward pass (see ``run_parallel``): yields after every GEMM request.
     x: NHWC [B,H,W,Cp] fp32 CUDA.  Returns (y_last, saved list).
 
@@ -447,6 +447,8 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
     ``first_mask_applied``: the input already carries the first stage's Dropout2d mask (it was folded into the
     producers that way); the mask is still drawn, in order, and saved for the backward pass.
     ``lane`` (dropout.Lane): the chain's Dropout2d masks are the requests of that lane (chains advanced side by side).
+    ``alloc(tag, shape)``: where the stage outputs live instead of fresh tensors (persistent buffers of a forward pass
+    that is computed ahead of its iteration, AliStepper.pipeline_reduce).
 
     ``groups`` > 1: the batch holds that many independent forward passes back to back (equal sample counts).  The
     convolutions run once over all of them; BatchNorm takes its batch statistics -- and updates the running ones --
@@ -511,7 +513,8 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
             y = joint[:, joff:joff + out_shape[3]].unflatten(1, (1, 1, out_shape[3]))     # [B,1,1,K] view, rows out_ld apart
             jmask = None if jm is None else jm[:, joff:joff + out_shape[3]]
         else:
-            y = torch.empty(out_shape, dtype=torch.float32, device=cur.device)
+            y = (alloc(("y", si), out_shape) if alloc is not None
+                 else torch.empty(out_shape, dtype=torch.float32, device=cur.device))
         nk = [p[0] for p in nxt.pre] if nxt is not None else []
         plain_gemm = st.kind in ("conv", "convT") and not _is_tconv1(st, Cp) and not _scatter_fwd(st, Cp)
         # A lone Dropout2d in front of the next stage multiplies this stage's output by a per-(sample, channel)
@@ -549,7 +552,8 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
             m = st.mod
             R, S = m.kernel_size
             Co = m.out_channels
-            contrib = torch.empty(B, H, W, Co * R * S, dtype=torch.float32, device=cur.device)
+            contrib = (alloc(("contrib", si), (B, H, W, Co * R * S)) if alloc is not None
+                       else torch.empty(B, H, W, Co * R * S, dtype=torch.float32, device=cur.device))
             ops.conv_fwd(ops.geom(B, H, W, Cp, H, W, Co * R * S, 1, 1, 1, 0), t, plan.packed(st, "scatter", Cp), contrib,
                          ops.epilogue(), live=(c_log, None))
             yield

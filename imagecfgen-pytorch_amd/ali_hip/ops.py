@@ -439,7 +439,9 @@ def _f16_operands(g, which, x, w_packed, y, ep):
     if x16 is not None and w16 is not None:
         ep.in16, ep.w16 = c_void_p(x16.data_ptr()), c_void_p(w16.data_ptr())
     if not ep.out_ld and _lib.load().ali_conv_writes_out16(byref(g), which):
-        y16 = torch.empty(y.shape, dtype=torch.float16, device=y.device)
+        y16 = shadow16(y)                # (a persistent output buffer keeps its twin: fixed addresses for captured graphs)
+        if y16 is None or y16.dtype != torch.float16:
+            y16 = torch.empty(y.shape, dtype=torch.float16, device=y.device)
         ep.out16 = c_void_p(y16.data_ptr())
         y._ali16 = y16
 
@@ -986,7 +988,7 @@ def attr_pack(cats, conts, B, device):
     return idx, cont
 
 
-def g_input(z, onehots, tables, cont, ld):
+def g_input(z, onehots, tables, cont, ld, out=None):
     """Generator input rows [B, ld] = [z | onehot_j @ table_j | cont | 0] in one launch (ali_g_input)."""
     lib = _lib.load()
     B, zdim = z.shape
@@ -994,7 +996,8 @@ def g_input(z, onehots, tables, cont, ld):
     for t in tables:
         _chk(t, "embedding table")
     tptr = (c_void_p * max(len(tables), 1))(*[t.data_ptr() for t in tables])
-    out = torch.empty(B, ld, dtype=torch.float32, device=z.device)
+    if out is None:
+        out = torch.empty(B, ld, dtype=torch.float32, device=z.device)
     _lib.check(lib.ali_g_input(_chk(z, "z"), zdim, ptrs, ncls, isint, tptr, len(tables), _opt(cont, "cont"),
                                0 if cont is None else cont.shape[1], B, ld, _chk(out), _stream()), "ali_g_input")
     return out

@@ -168,14 +168,15 @@ def _attr2d(t, B, as_float=False):
     return t.reshape(B, -1).contiguous()
 
 
-def _g_input(fam, z, onehots, cont):
+def _g_input(fam, z, onehots, cont, alloc=None):
     """[z | onehot @ table ... | cont | 0 pad] rows of the Generator's first layer (mnist.py:76-85), one launch;
     channel stride % 32 == 0 -> uniform-tap fast path of the GEMM kernel.  Returns ([B,1,1,ld], logical width)."""
     B = z.shape[0]
     z = z.reshape(B, -1).float().contiguous()
     n_log = z.shape[1] + 256 * len(fam.g_tables) + (0 if cont is None else cont.shape[1])
     ld = n_log + (-n_log) % 32
-    return ops.g_input(z, onehots, [t.detach() for t in fam.g_tables], cont, ld).reshape(B, 1, 1, ld), n_log
+    out = alloc("gin", (B, ld)) if alloc is not None else None
+    return ops.g_input(z, onehots, [t.detach() for t in fam.g_tables], cont, ld, out=out).reshape(B, 1, 1, ld), n_log
 
 
 def family_of(E, G, D):
@@ -184,13 +185,20 @@ def family_of(E, G, D):
 
 class AliStepper:
     def __init__(self, E, G, D, lr=1e-4, betas=(0.5, 0.999), eps=1e-8, family=None, process_group=None,
-                 capture=False, precision="f32", loss_scale=None):
+                 capture=False, precision="f32", loss_scale=None, pipeline_reduce=False):
         """``precision="f16"``: the convolutions' forward and data-gradient GEMMs contract fp16 operands on
         v_mfma_f32_32x32x16_f16 with fp32 accumulation (BASELINE config 5); activations, master weights, weight
         gradients' accumulation and Adam stay fp32.  The three losses' gradients are multiplied by ``loss_scale``
         (default 1024 for f16, 1 otherwise; a power of two) so that small gradients survive the fp16 rounding of the
         GEMM operands, and Adam divides it out again."""
         self.E, self.G, self.D = E, G, D
+        # Data parallel only: overlap the LAST all-reduce of an iteration (D step b) with the NEXT iteration's E(x) / G(z)
+        # forward passes, which need neither that reduction nor the D update behind it (SURVEY.md 8e).  ``step(...,
+        # ahead=(images, c, z))`` names the next batch; its forward is computed into persistent buffers while the
+        # collective runs and consumed by the next ``step``.  Same arithmetic, same results (tests/test_gpu_dp.py).
+        self.pipeline_reduce = bool(pipeline_reduce)
+        self._ahead = None            # {"key": ..., "fwd": (ex, sE, gz, sG, n_log, g_log)} of the batch computed ahead
+        self._arena = {}              # persistent outputs of the ahead-of-time forward: {(tag, shape): tensor}
         self.precision = precision
         self.loss_scale = float(loss_scale if loss_scale is not None else (1024.0 if precision == "f16" else 1.0))
         self.family = family or family_of(E, G, D)
@@ -280,8 +288,42 @@ class AliStepper:
         for j, t in enumerate(tables):
             ops.plane_table_grad(g0, gofs + j, None, 1 + j, idx, j, t.shape[0], out=dst[id(t)], table=t.detach())
 
-    def _g_input(self, z, onehots, cont):
-        return _g_input(self.family, z, onehots, cont)
+    def _g_input(self, z, onehots, cont, alloc=None):
+        return _g_input(self.family, z, onehots, cont, alloc)
+
+    # ---- the E(x) / G(z) forward of the E+G phase, computable ahead of its iteration (pipeline_reduce)
+    def _arena_alloc(self, chain):
+        def alloc(tag, shape):
+            key = (chain, tag, tuple(int(v) for v in shape))
+            t = self._arena.get(key)
+            if t is None:
+                t = self._arena[key] = torch.empty(key[2], dtype=torch.float32, device=self.opt_d.flat.device)
+            return t
+        return alloc
+
+    def _eg_forward(self, images, idx, cont, onehots, zin, alloc_e=None, alloc_g=None):
+        """E(x) and G(z) with their saved activations: independent chains, layer pairs share a launch"""
+        fam = self.family
+        x0e, n_log = self._planes(images, idx, cont, fam.e_tables,
+                                  out=None if alloc_e is None else alloc_e("x0", (images.shape[0],) + tuple(fam.hw) + (
+                                      (1 + len(fam.e_tables) + (0 if cont is None else cont.shape[1]) + 3) // 4 * 4,)))
+        gin, g_log = self._g_input(zin, onehots, cont, alloc_g)
+        (ex, sE), (gz, sG) = run_parallel(chain_forward_gen(self.pE, x0e, True, n_log, True, alloc=alloc_e),
+                                          chain_forward_gen(self.pG, gin, True, g_log, True, alloc=alloc_g))
+        return ex, sE, gz, sG, n_log, g_log
+
+    @staticmethod
+    def _batch_key(images, z):
+        return (images.data_ptr(), tuple(images.shape), z.data_ptr(), tuple(z.shape))
+
+    def _prefetch(self, images, c, z):
+        """compute the E+G phase's forward passes for a batch ahead of its iteration, into persistent buffers"""
+        B = images.shape[0]
+        idx, cont, onehots = self.family.conditioning(c)
+        zin = z.reshape(B, -1).float().contiguous()
+        with ops.precision(self.precision):
+            fwd = self._eg_forward(images, idx, cont, onehots, zin, self._arena_alloc("E"), self._arena_alloc("G"))
+        self._ahead = {"key": self._batch_key(images, z), "fwd": fwd}
 
     def _join_begin(self, B, device):
         """(joint buffer [B, n_dx + nz], the Dropout2d mask of dxz's first stage) for a D forward that is about to
@@ -418,11 +460,9 @@ class AliStepper:
         """E+G gradients (reference mnist.py:224-229)."""
         fam, images, idx, cont, onehots, zin, B = (self.family, cx["images"], cx["idx"], cx["cont"], cx["onehots"],
                                                    cx["zin"], cx["B"])
-        x0e, n_log = self._planes(images, idx, cont, fam.e_tables)
-        gin, g_log = self._g_input(zin, onehots, cont)
-        # E(x) and G(z) are independent chains: layer pairs share a launch (chain.run_parallel)
-        (ex, sE), (gz, sG) = run_parallel(chain_forward_gen(self.pE, x0e, True, n_log, True),
-                                          chain_forward_gen(self.pG, gin, True, g_log, True))
+        # E(x) and G(z): computed here, or ahead of the iteration (pipeline_reduce)
+        fwd = cx.pop("eg_fwd", None)
+        ex, sE, gz, sG, n_log, g_log = fwd if fwd is not None else self._eg_forward(images, idx, cont, onehots, zin)
         # D(x, E(x)) and D(G(z), z) share the weights: one batch of 2B samples (reference order: real pass first)
         logits, (s_dx, s_dz, s_dxz, n_dx, _) = self._d_forward_pair(images, ex.reshape(zin.shape), gz, zin, idx, cont, True)
         # (bce(D_valid, 0) + bce(D_fake, 1)) / 2 and its gradient for both halves: one launch
@@ -563,7 +603,10 @@ class AliStepper:
             # replicas use local batch statistics; keep the running buffers (state_dict) identical
             dp.average_buffers_(self.bn_buffers, self.pg)
 
-    def _segments(self, do_eg):
+    def _pipelined(self, do_eg):
+        return self.pipeline_reduce and do_eg and (self.dist or self.segmented)
+
+    def _segments(self, do_eg, ahead=False):
         """The iteration as a list of (work, reduce, wait) steps.  ``work(cx)`` is pure device work (capturable in a HIP
         graph); ``reduce`` names the parameter group whose flat gradient buffer is all-reduced -- asynchronously, on
         the collective's own stream -- right after the step; a step with ``wait`` first makes the compute stream wait
@@ -584,13 +627,30 @@ class AliStepper:
             segs.append((lambda cx: (self._d_real_pre(cx), self._d_real_rest(cx)), self.opt_d, False))
         segs.append((lambda cx: self._d_fake_pre(cx), None, False))
         segs.append((lambda cx: (self._apply_d(), self._d_fake_rest(cx)), self.opt_d, True))
+        if ahead and self._pipelined(do_eg):
+            # the NEXT iteration's E(x) / G(z) forward passes run under the all-reduce that was just issued: they need
+            # neither it nor the D update behind it (pipeline_reduce)
+            segs.append((lambda cx: self._prefetch(*cx["ahead"]), None, False))
         segs.append((lambda cx: (self._apply_d(), self._phase_scores(cx, average_bn=False)), None, True))
         return segs
 
-    def _iteration(self, images, c, z, do_eg=True):
+    def _take_ahead(self, cx, images, c, z):
+        """pipeline_reduce: the E+G phase consumes the forward passes computed ahead (by the previous ``step``'s tail,
+        or right here when this batch was not announced)"""
+        if self._ahead is None or self._ahead["fwd"] is None or self._ahead["key"] != self._batch_key(images, z):
+            self._prefetch(images, c, z)
+        cx["eg_fwd"], self._ahead = self._ahead["fwd"], None
+
+    def _iteration(self, images, c, z, do_eg=True, ahead=None):
+        pipe = self._pipelined(do_eg)
+        if pipe and (self._ahead is None or self._ahead["fwd"] is None or self._ahead["key"] != self._batch_key(images, z)):
+            self._prefetch(images, c, z)       # (in front of _begin: it runs its own attribute plumbing)
         cx = self._begin(images, c, z, do_eg)
+        if pipe:
+            self._take_ahead(cx, images, c, z)
+            cx["ahead"] = ahead
         pending = None
-        for work, group, wait in self._segments(do_eg):
+        for work, group, wait in self._segments(do_eg, ahead is not None):
             if wait and pending is not None:
                 pending.wait()
                 pending = None
@@ -696,26 +756,30 @@ class AliStepper:
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
-    def step(self, images, c: Dict[str, torch.Tensor], z, do_eg=True, masks=None):
-        """One iteration.  ``masks``: optional list of host-recorded Dropout2d masks (parity mode)."""
+    def step(self, images, c: Dict[str, torch.Tensor], z, do_eg=True, masks=None, ahead=None):
+        """One iteration.  ``masks``: optional list of host-recorded Dropout2d masks (parity mode).
+        ``ahead`` = (images, c, z) of the NEXT call (``pipeline_reduce``, data parallel only; ignored otherwise): pass
+        the very tensors the next call will be given."""
         try:
-            return self._step(images, c, z, do_eg, masks)
+            return self._step(images, c, z, do_eg, masks, ahead)
         finally:
             _chain.abort_batch_counts()     # no-op after a completed iteration
 
-    def _step(self, images, c, z, do_eg, masks):
+    def _step(self, images, c, z, do_eg, masks, ahead=None):
         with ops.precision(self.precision):
-            return self._step_impl(images, c, z, do_eg, masks)
+            return self._step_impl(images, c, z, do_eg, masks, ahead)
 
-    def _step_impl(self, images, c, z, do_eg, masks):
+    def _step_impl(self, images, c, z, do_eg, masks, ahead=None):
+        if not self._pipelined(do_eg):
+            ahead = None
         if masks is not None:
             with _dropout.injected_masks(masks):
-                return self._iteration(images, c, z, do_eg)
+                return self._iteration(images, c, z, do_eg, ahead)
         if not self.capture:
-            return self._iteration(images, c, z, do_eg)
+            return self._iteration(images, c, z, do_eg, ahead)
         try:
             if self.dist or self.segmented:
-                return self._replay_segments(images, c, z, do_eg)
+                return self._replay_segments(images, c, z, do_eg, ahead)
             return self._replay(images, c, z, do_eg)
         except RuntimeError as e:  # graph capture refused (driver / RCCL combination): keep training, eagerly
             if self._graph or not any(w in str(e).lower() for w in ("captur", "graph")):
@@ -727,26 +791,34 @@ class AliStepper:
                 self._restore(self._capture_snapshot)
             return self._iteration(images, c, z, do_eg)
 
-    def _replay_segments(self, images, c, z, do_eg):
+    def _replay_segments(self, images, c, z, do_eg, ahead=None):
         """Data-parallel replay: one HIP graph per segment, the gradient all-reduces in between launched eagerly."""
-        key = ("seg", tuple(images.shape), do_eg)
+        pipe = self._pipelined(do_eg)
+        key = ("seg", tuple(images.shape), do_eg, pipe, ahead is not None)
         if key not in self._graph:
             st = {"images": images.clone(), "z": z.clone(), "c": {k: v.clone() for k, v in c.items()}}
+            nxt = None
+            if ahead is not None:
+                nxt = (ahead[0].clone(), {k: v.clone() for k, v in ahead[1].items()}, ahead[2].clone())
             snap = self._snapshot()
             self._capture_snapshot = snap
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):          # warm-up outside capture (collectives included: all ranks do this)
-                self._iteration(st["images"], st["c"], st["z"], do_eg)
+                self._iteration(st["images"], st["c"], st["z"], do_eg, nxt)
+                if pipe and self._ahead is None:
+                    self._prefetch(st["images"], st["c"], st["z"])     # the persistent buffers the capture will name
             torch.cuda.current_stream().wait_stream(s)
             self._restore(snap)
             pool = torch.cuda.graph_pool_handle()
             graphs, cx = [], None
-            for i, (fn, group, wait) in enumerate(self._segments(do_eg)):
+            for i, (fn, group, wait) in enumerate(self._segments(do_eg, ahead is not None)):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     if i == 0:
                         cx = self._begin(st["images"], st["c"], st["z"], do_eg)
+                        if pipe:
+                            cx["eg_fwd"], cx["ahead"] = self._ahead["fwd"], nxt      # (the persistent buffers)
                     fn(cx)
                 graphs.append((g, group, wait))
                 if group is not None and self.dist:   # keep the ranks' collective sequences aligned while capturing
@@ -754,9 +826,15 @@ class AliStepper:
             if self.dist:
                 dp.average_buffers_(self.bn_buffers, self.pg)
             self._restore(snap)                 # capture executes nothing, but the eager collectives above ran
-            self._graph[key] = (graphs, st, cx["out"])
-        graphs, st, res = self._graph[key]
+            self._ahead = None                  # (what the buffers hold was computed with the warm-up's weights)
+            self._graph[key] = (graphs, st, cx["out"], nxt)
+        graphs, st, res, nxt = self._graph[key]
         ops.copy_multi([(st["images"], images), (st["z"], z)] + [(st["c"][k], v) for k, v in c.items()])
+        if nxt is not None:
+            ops.copy_multi([(nxt[0], ahead[0]), (nxt[2], ahead[2])] + [(nxt[1][k], v) for k, v in ahead[1].items()])
+        if pipe and (self._ahead is None or self._ahead["key"] != self._batch_key(images, z)):
+            self._prefetch(st["images"], st["c"], st["z"])      # this batch was not announced: compute its forward now
+        self._ahead = None
         pending = None
         for g, group, wait in graphs:
             if wait and pending is not None:
@@ -767,6 +845,8 @@ class AliStepper:
                 pending = dp.allreduce_sum_async_(group.grad, self.pg)
         if self.dist:
             dp.average_buffers_(self.bn_buffers, self.pg)
+        if pipe and ahead is not None:          # the replayed prefetch segment left the next batch's forward in the buffers
+            self._ahead = {"key": self._batch_key(ahead[0], ahead[2]), "fwd": None}
         return res
 
     def _replay(self, images, c, z, do_eg):

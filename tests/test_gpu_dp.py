@@ -34,7 +34,7 @@ def _paths():
             sys.path.insert(0, p)
 
 
-def _replica(rank, process_group, capture):
+def _replica(rank, process_group, capture, pipeline=False):
     """Identical weights on every rank (seed 7); shard, z and dropout seed by rank."""
     _paths()
     import ali_hip
@@ -48,7 +48,7 @@ def _replica(rank, process_group, capture):
         orc.rescale_for_test_(m, 0.01, bias_seed=7 + i)
         m.cuda().train()
     ali_hip.manual_seed(11 + rank)
-    st = AliStepper(E, G, D, process_group=process_group, capture=capture)
+    st = AliStepper(E, G, D, process_group=process_group, capture=capture, pipeline_reduce=pipeline)
     x, a = orc.synth_morphomnist(2 * BS, seed=1)
     stats = {k: (v.min(dim=0).values, v.max(dim=0).values) for k, v in a.items() if k != "digit"}
     lo = rank * BS
@@ -64,16 +64,16 @@ def _digest(st, D):
     return orc.tensor_digest(torch.cat([t.reshape(-1).cpu() for t in state]))
 
 
-def _worker(rank, world, port, capture, iters, out_dir):
+def _worker(rank, world, port, capture, iters, out_dir, pipeline=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     torch.set_num_threads(2)
-    st, D, (images, c, z) = _replica(rank, dist.group.WORLD, capture)
+    st, D, (images, c, z) = _replica(rank, dist.group.WORLD, capture, pipeline)
     out = None
-    for _ in range(iters):
-        out = st.step(images, c, z)
+    for _ in range(iters):       # (pipelined: every step announces the next batch -- here the same tensors again)
+        out = st.step(images, c, z, ahead=(images, c, z) if pipeline else None)
     torch.save({"digest": _digest(st, D), "out": {k: float(v) for k, v in out.items()}},
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
@@ -144,11 +144,13 @@ def _emulate(world, iters):
     return [_digest(st, D) for st, D, *_ in reps], outs
 
 
-@pytest.mark.parametrize("capture", [False, True])
-def test_stepper_two_ranks_own_shards_vs_emulation(tmp_path, capture):
+@pytest.mark.parametrize("capture,pipeline", [(False, False), (True, False), (False, True), (True, True)])
+def test_stepper_two_ranks_own_shards_vs_emulation(tmp_path, capture, pipeline):
+    """``pipeline``: AliStepper(pipeline_reduce=True) -- the last all-reduce of an iteration overlaps with the next
+    iteration's E(x) / G(z) forward passes; same result as the plain data-parallel schedule, bit for bit."""
     iters = 3
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, capture, iters, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, capture, iters, str(tmp_path), pipeline), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"r{i}.pt") for i in range(2))
     assert r0["digest"] == r1["digest"], "replicas diverged"
     assert r0["out"] != r1["out"], "the ranks were supposed to see different shards"

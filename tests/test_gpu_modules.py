@@ -641,6 +641,28 @@ def test_spect_stepper_iteration_vs_oracle(family, d, B):
         assert err.mean().item() <= 0.02 * lr, (nm, err.mean().item())
 
 
+@pytest.mark.parametrize("capture", [False, True])
+def test_pipelined_last_allreduce_schedule_equals_plain(capture):
+    """AliStepper(pipeline_reduce=True): the next iteration's E(x) / G(z) forward passes are computed at the tail of the
+    current iteration (where a data-parallel run has its last all-reduce in flight), into persistent buffers, and
+    consumed by the next step -- the same arithmetic in another order: bit-identical to the plain schedule, with the
+    next batch announced (``ahead``) or not, eager and replayed from the per-segment HIP graphs."""
+    import ali_hip
+    ali_hip.manual_seed(5)
+    _, _, a, batches = _stepper_setup(capture=False, bs=64, n=4)
+    ali_hip.manual_seed(5)
+    _, _, b, _ = _stepper_setup(capture=capture, bs=64, n=4)
+    b.segmented, b.pipeline_reduce = True, True
+    dev = [(im.cuda(), to_dev(c), z.cuda()) for im, c, z in batches]
+    for i, (images, c, z) in enumerate(dev):
+        r1 = {k: v.item() for k, v in a.step(images, c, z).items()}
+        nxt = dev[i + 1] if i + 1 < len(dev) and i != 1 else None       # (iteration 2's batch comes unannounced)
+        r2 = {k: v.item() for k, v in b.step(images, c, z, ahead=nxt).items()}
+        assert r1 == r2, (i, r1, r2)
+    assert torch.equal(a.opt_d.flat, b.opt_d.flat) and torch.equal(a.opt_eg.flat, b.opt_eg.flat)
+    assert len(b._arena) >= 8
+
+
 def test_segmented_graph_replay_equals_eager():
     """The data-parallel replay (one HIP graph per segment, collectives in between) on one rank == eager."""
     import ali_hip
