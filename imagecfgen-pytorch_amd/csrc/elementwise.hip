@@ -852,13 +852,22 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
   const long long npix = (long long)B * H * W;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
+  const bool small = npix < (1LL << 31);       // 32-bit index arithmetic (64-bit divisions cost hundreds of cycles each)
   for (; i < npix; i += step) {
-    const int w = (int)(i % W);
-    const long long t2 = i / W;
-    const int h = (int)(t2 % H);
-    const int b = (int)(t2 / H);
+    int w, h, b;
+    if (small) {
+      const unsigned iu = (unsigned)i, t2 = iu / (unsigned)W;
+      w = (int)(iu - t2 * (unsigned)W);
+      b = (int)(t2 / (unsigned)H);
+      h = (int)(t2 - (unsigned)b * (unsigned)H);
+    } else {
+      w = (int)(i % W);
+      const long long t2 = i / W;
+      h = (int)(t2 % H);
+      b = (int)(t2 / H);
+    }
     // nearest: src = floor(dst * 16 / size)  (torch 'nearest', probe-verified in SURVEY.md K8)
-    const int sh = (int)(((long long)h * 16) / H), sw = (int)(((long long)w * 16) / W);
+    const int sh = (h * 16) / H, sw = (w * 16) / W;
     float* o = out + i * Cpad;
     if (Cpad == 8) {                     // the MNIST stacks' 5 planes in 8 channels: two 16-byte stores per pixel
       float v[8];
