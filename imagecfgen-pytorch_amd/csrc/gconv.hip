@@ -789,7 +789,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
               if (partial) __hip_atomic_store(outp + roff[q] + n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               else {
                 outp[roff[q] + n] = v;
-                if (F16 != 0 && d.out16) d.out16[roff[q] + n] = (_Float16)v;
+                if (d.out16) d.out16[roff[q] + n] = (_Float16)v;
               }
               if (BNM == 1) {
                 const float vs = v * bm1[q];
@@ -1171,7 +1171,8 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   if (tiles == 0 || d.out_elems == 0) return ALI_OK;
   const bool f16 = d.f16 && uni;
   const bool op16 = f16 && d.in16 && d.w16 && (d.Cin % 64) == 0;
-  if (!f16) d.out16 = nullptr;      // only the fp16 kernels write the shadow
+  if (!d.f16) d.out16 = nullptr;    // twins are left by mfma_f16 launches only -- also by those of them that keep fp32
+                                    // arithmetic (first layers): their consumers then read fp16 operands from memory
   if (job && uni && !f16 && ((tc.bm == 64 && tc.bn == 64) || (tc.bm == 128 && tc.bn == 32))) {
     GJobRec r;
     memset(&r, 0, sizeof(r));
@@ -1513,9 +1514,8 @@ extern "C" int32_t ali_conv_tile_order(const AliConvGeom* g, int32_t which, int3
 }
 
 extern "C" int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which) {
-  if (!geom_ok(g)) return 0;
-  const int cin = which == 0 ? g->C : g->K;      // channel stride of the gathered operand
-  return (cin % BK) == 0 ? 1 : 0;
+  (void)which;
+  return geom_ok(g) ? 1 : 0;       // every mfma_f16 launch of the GEMM kernel does, whatever arithmetic its loop uses
 }
 
 static int conv_fwd_impl(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,

@@ -96,7 +96,8 @@ typedef struct {
   /* fp16 twins (mfma_f16 launches only; all optional): in16 / w16 = the gathered operand and the packed weights as
    * fp16 arrays of the same shapes -- when both are given and the input channel stride % 64 == 0 the kernel reads them
    * instead of x / w (half the bytes, no conversion); out16 = where to leave the fp16 twin of the output for the next
-   * layer.  A launch that cannot run on fp16 MFMA ignores all three (out16 is then NOT written: ali_conv_writes_out16). */
+   * layer.  A launch that cannot run on fp16 MFMA (first layers: 4-8 input channels) ignores in16 / w16 and keeps fp32
+   * arithmetic, but still leaves out16, so that the layer behind it reads fp16 operands (ali_conv_writes_out16). */
   const void* in16;
   const void* w16;
   void* out16;
@@ -169,8 +170,8 @@ int32_t ali_conv_mtiles(const AliConvGeom* g, int32_t which, int32_t mfma_f16, i
  * number; 0 when all tiles cost the same or the launch cannot use an order.  Upload once per geometry and pass as
  * AliEpilogue.tile_order. */
 int32_t ali_conv_tile_order(const AliConvGeom* g, int32_t which, int32_t mfma_f16, int32_t* order, int32_t cap);
-/* 1 if the launch ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) makes for g with mfma_f16 = 1 runs on
- * fp16 MFMA, i.e. writes AliEpilogue.out16. */
+/* 1 if the launch ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) makes for g with mfma_f16 = 1 writes
+ * AliEpilogue.out16 (every valid geometry does). */
 int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which);
 int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w_kxc, float* y,
                  const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
