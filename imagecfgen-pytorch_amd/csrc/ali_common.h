@@ -31,6 +31,7 @@ struct Tuning {
                                             // times larger (tests: a small batch runs the tiles of the bench batch)
   int wbm, wbn;                             // ALI_WBM / ALI_WBN: force the weight-gradient tile (one of its variants)
   int no_xcd;                               // ALI_NO_XCD=1: raster tile order on deep grids instead of XCD-contiguous chunks (A/B)
+  int no_s2_first;                          // ALI_NO_S2_FIRST=1: the spectrogram stacks' first conv stays an implicit GEMM (A/B)
   int no_t1_mfma;                           // ALI_NO_T1_MFMA=1: the VALU gather forms of the direct one-channel kernels (A/B)
 };
 inline Tuning read_tuning() {
@@ -46,6 +47,7 @@ inline Tuning read_tuning() {
     v.wbm = (int)num("ALI_WBM"); v.wbn = (int)num("ALI_WBN");
     v.no_t1_mfma = (int)num("ALI_NO_T1_MFMA");
     v.no_xcd = (int)num("ALI_NO_XCD");
+    v.no_s2_first = (int)num("ALI_NO_S2_FIRST");
     return v;
   }
 }

@@ -1380,6 +1380,122 @@ static int conv_first_launch(const AliConvGeom* g, const float* x, const float* 
   return check_launch("conv_first_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// First Conv2d of the spectrogram stacks (audio_mnist.py:186, whalecalls.py / esrf_acoustic.py copies: 1 + n attribute
+// planes, padded to 4 or 8 channels, -> 64 channels, 5x5, stride 2, pad 1, on 128^2 ... 512^2 maps).  As an implicit GEMM
+// its k-loop is 4-7 tiles long and 65 k blocks spend their time in prologue and epilogue: 1.05 ms per ESRF launch
+// (50 TF/s, 1.3 TB/s) against 0.34 ms of fp32 MFMA work and 0.3 ms of output traffic.  Here a wave owns 32 output pixels of
+// one row x all 64 channels and walks along the row; the 64 x 25 x C weights sit in LDS once per block (4 rows x the
+// whole row length), the input is gathered straight from memory into MFMA operand registers (buffer loads, hardware range
+// check for the padding): lane (m, h) loads channels [4h', 4h'+4) of tap t for pixel m -- one 16-byte load = the k-slots of
+// four v_mfma_f32_32x32x2_f32 steps (C = 4: the half-waves take taps 2j / 2j+1; C = 8: the two halves of tap j).  Same
+// arithmetic as the GEMM kernel (exact fp32 fma chain, k ascending), bias + activation epilogue, optional fp16 twin.
+struct S2Desc {
+  const float* in; const float* w; const float* bias; float* out; _Float16* out16;
+  int B, H, W, P, Q, pad, act; float slope;
+  unsigned in_bytes;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void conv_s2_first_kernel(const S2Desc d) {
+  constexpr int T = 25, K = 64;
+  constexpr int NP = C == 4 ? 13 : 25;                 // k-slot pairs: C = 4 (tap 2j | tap 2j+1), C = 8 (lo | hi half of tap j)
+  constexpr int LDW = T * C + (C == 8 ? 4 : 0);        // LDS row pitch: ds_read_b128 of 16 consecutive n conflict-free
+  extern __shared__ __attribute__((aligned(16))) float s2_w[];   // [64][LDW]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < K * T * C / 4; i += 256) {
+    const int n = i / (T * C / 4), rem = i - n * (T * C / 4);
+    *reinterpret_cast<f32x4*>(s2_w + n * LDW + rem * 4) = *reinterpret_cast<const f32x4*>(d.w + (long long)n * T * C + rem * 4);
+  }
+  __syncthreads();
+  const int m = lane & 31, h = lane >> 5;
+  const int prow = blockIdx.x * 4 + wave;               // this wave's output row (all waves stay for the barrier above)
+  const int b = blockIdx.y;
+  if (prow >= d.P) return;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, d.in_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  const float bias0 = d.bias ? d.bias[m] : 0.f, bias1 = d.bias ? d.bias[32 + m] : 0.f;
+  const int ih0 = prow * 2 - d.pad;
+  float* orow = d.out + ((long long)(b * d.P + prow) * d.Q) * K;
+  _Float16* orow16 = d.out16 ? d.out16 + ((long long)(b * d.P + prow) * d.Q) * K : nullptr;
+  for (int q0 = 0; q0 < d.Q; q0 += 32) {
+    const int q = q0 + m;
+    const int iw0 = q * 2 - d.pad;
+    int wsel = 0;
+    asm volatile("" : "+v"(wsel));     // (keeps the weight fragments' LDS reads inside the loop: hoisted, they cost 100-200 VGPRs)
+    const float* wl = s2_w + m * LDW + wsel;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // two batches of pairs: at most 13 gathers in flight per lane
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += 13) {
+      f32x4 a[13];
+#pragma unroll
+      for (int jj = 0; jj < 13; ++jj) {
+        const int j = j0 + jj;
+        if (j >= NP) break;
+        const int tap = C == 4 ? 2 * j + h : j;
+        const int r = tap / 5, sx = tap - r * 5;
+        const int ih = ih0 + r, iw = iw0 + sx;
+        const bool ok = tap < T && q < d.Q && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+        const unsigned off = ok ? (unsigned)((((b * d.H + ih) * d.W + iw) * C + (C == 8 ? 4 * h : 0)) * 4) : OOB;
+        a[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0));
+      }
+#pragma unroll
+      for (int jj = 0; jj < 13; ++jj) {
+        const int j = j0 + jj;
+        if (j >= NP) break;
+        const int tap = C == 4 ? 2 * j + h : j;
+        const int woff = (tap < T ? tap : 0) * C + (C == 8 ? 4 * h : 0);
+        f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + woff);
+        f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + 32 * LDW + woff);
+        if (tap >= T) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj][e], w0[e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj][e], w1[e], acc1, 0, 0, 0);
+        }
+      }
+    }
+    // acc(row = pixel (r&3) + 8*(r>>2) + 4*(lane>>5), col = channel lane&31): a store instruction writes two full
+    // 128-byte runs (measured against 16-byte stores of 4 channels per lane, which touch half a sector each: 732 vs 785 us)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (qq < d.Q) {
+        const float v0 = apply_act(acc0[r] + bias0, d.act, d.slope), v1 = apply_act(acc1[r] + bias1, d.act, d.slope);
+        orow[(long long)qq * K + m] = v0;
+        orow[(long long)qq * K + 32 + m] = v1;
+        if (orow16) { orow16[(long long)qq * K + m] = (_Float16)v0; orow16[(long long)qq * K + 32 + m] = (_Float16)v1; }
+      }
+    }
+  }
+}
+
+static bool conv_s2_first_ok(const AliConvGeom* g, const AliEpilogue* ep) {
+  if (tuning().no_s2_first) return false;
+  if ((g->C != 4 && g->C != 8) || g->K != 64 || g->R != 5 || g->S != 5 || g->stride != 2 || g->pad > 2) return false;
+  if (g->P != (g->H + 2 * g->pad - 5) / 2 + 1 || g->Q != (g->W + 2 * g->pad - 5) / 2 + 1 || g->Q < 32 || g->B > 65535) return false;
+  if ((long long)g->B * g->H * g->W * g->C >= (1LL << 29)) return false;       // 32-bit byte offsets
+  if (ep && (ep->mask || ep->dact_y || ep->bn_part || ep->in_ld || ep->out_ld || ep->tile_order_n < 0)) return false;
+  return true;
+}
+
+static int conv_s2_first_launch(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,
+                                hipStream_t stream) {
+  S2Desc d;
+  memset(&d, 0, sizeof(d));
+  d.in = x; d.w = w; d.out = y;
+  if (ep) { d.bias = ep->bias; d.act = ep->act; d.slope = ep->slope; if (ep->mfma_f16) d.out16 = reinterpret_cast<_Float16*>(ep->out16); }
+  d.B = g->B; d.H = g->H; d.W = g->W; d.P = g->P; d.Q = g->Q; d.pad = g->pad;
+  d.in_bytes = (unsigned)((long long)g->B * g->H * g->W * g->C * 4);
+  dim3 grid((g->P + 3) / 4, g->B);
+  if (g->C == 4) hipLaunchKernelGGL(conv_s2_first_kernel<4>, grid, dim3(256), (size_t)64 * 100 * sizeof(float), stream, d);
+  else hipLaunchKernelGGL(conv_s2_first_kernel<8>, grid, dim3(256), (size_t)64 * 204 * sizeof(float), stream, d);
+  return check_launch("conv_s2_first_kernel");
+}
+
 static void setup_fwd(const AliConvGeom* g, GDesc& d) {
   d.B = g->B; d.Hin = g->H; d.Win = g->W; d.Cin = g->C;
   d.Hout = g->P; d.Wout = g->Q; d.Cout = g->K; d.ldo = g->K;
@@ -1534,6 +1650,7 @@ static int conv_fwd_impl(const AliConvGeom* g, const float* x, const float* w, f
     if (ep && ep->bn_part) { set_error("ali_conv_fwd: epilogue not supported for this first-layer geometry"); return ALI_ERR_BAD_ARG; }
     // (no partials requested: the GEMM kernel serves the epilogue the per-image kernel cannot)
   }
+  if (conv_s2_first_ok(g, ep)) return conv_s2_first_launch(g, x, w, y, ep, (hipStream_t)stream);
   GDesc d;
   memset(&d, 0, sizeof(d));
   d.in = x; d.w = w; d.out = y;

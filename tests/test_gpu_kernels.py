@@ -75,6 +75,8 @@ CONV_CASES = [
     (512, 256, 3, 512, 4, 2, 1),   # split-K path at the bench batch
     (70, 5, 28, 32, 5, 1, 0), (64, 7, 20, 32, 3, 1, 0),   # per-image first-layer kernel (B >= 64, 8 -> 32 channels)
     (64, 5, 9, 32, 5, 1, 0), (130, 8, 12, 32, 5, 1, 0),
+    # first layers of the spectrogram stacks (3 / 7 planes -> 64 channels, 5x5 stride 2 pad 1): the row-walking kernel
+    (3, 3, 67, 64, 5, 2, 1), (2, 7, 66, 64, 5, 2, 1), (5, 4, 131, 64, 5, 2, 1), (2, 8, 70, 64, 5, 2, 2),
 ]
 
 
