@@ -102,7 +102,7 @@ SIGNATURES = {
     "ali_g_input_table_grad": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                          c_void_p]),
     "ali_adam": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
-                           c_int32, c_void_p, c_void_p, c_float, c_void_p]),
+                           c_int32, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "ali_add_i64_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "ali_assemble_planes": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_int32, c_void_p,
                                       c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),

@@ -183,11 +183,17 @@ class ChainPlan:
             ops.pack_weights(fwd, out, I, 1, O, O, 1, 0, cin_stride)
             return out
 
-        if which == "fwd" and not ops._PRECISION["f16"] and w.dim() == 4 and tuple(w.stride()) == _fwd_pack_strides(st) \
+        twin = getattr(w, "_ali_flat16", None)
+        if which == "fwd" and (not ops._PRECISION["f16"] or twin is not None) and w.dim() == 4 \
+                and tuple(w.stride()) == _fwd_pack_strides(st) \
                 and cin_stride == (w.shape[1] if st.kind == "conv" else w.shape[0]):
-            # the master weights ARE the forward pack (FlatGroup.layouts): no copy to refresh
+            # the master weights ARE the forward pack (FlatGroup.layouts): no copy to refresh.  fp16-MFMA path: the Adam
+            # launch keeps an fp16 twin of the flat parameter buffer (FlatGroup.flat16); its segment is the pack's twin
             n_out = w.shape[0] if st.kind == "conv" else w.shape[1]
-            return _storage_view(w).view(n_out, w.shape[2] * w.shape[3], cin_stride)
+            alias = _storage_view(w).view(n_out, w.shape[2] * w.shape[3], cin_stride)
+            if ops._PRECISION["f16"]:
+                alias._ali16 = twin.view(n_out, w.shape[2] * w.shape[3], cin_stride)
+            return alias
         val = self.cache.get((st.index, which, cin_stride), w, build)
         if ops._PRECISION["f16"] and which in ("fwd", "dgrad"):
             with torch.no_grad():

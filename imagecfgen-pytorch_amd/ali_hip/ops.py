@@ -1012,9 +1012,9 @@ def g_input_table_grad(onehot, g, off, out):
     return out
 
 
-def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0, arrive=None):
-    """``arrive`` (zeroed int32 device tensor): ``dev_step`` counts COMPLETED steps and the launch advances it itself
-    (include/ali_hip.h: ali_adam)."""
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0, arrive=None, p16=None):
+    """``arrive`` (zeroed int32 device tensor): ``dev_step`` counts COMPLETED steps and the launch advances it itself;
+    ``p16`` (fp16, same numel): the launch also leaves the fp16 twin of the updated parameters (include/ali_hip.h: ali_adam)."""
     lib = _lib.load()
     ds = ar = None
     if dev_step is not None:
@@ -1024,7 +1024,8 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, step, dev_step=None, grad_scale=1.0,
         assert arrive.is_cuda and arrive.dtype == torch.int32 and dev_step is not None
         ar = c_void_p(arrive.data_ptr())
     _lib.check(lib.ali_adam(_chk(p, "p"), _chk(g, "g"), _chk(m, "m"), _chk(v, "v"), p.numel(), lr, beta1, beta2, eps,
-                            step, ds, ar, grad_scale, _stream()), "ali_adam")
+                            step, ds, ar, grad_scale, None if p16 is None else c_void_p(p16.data_ptr()), _stream()),
+               "ali_adam")
 
 
 def add_i64_multi(counters, incs):

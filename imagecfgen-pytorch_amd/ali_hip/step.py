@@ -40,12 +40,16 @@ class FlatGroup:
     optimiser step itself leaves the weights in kernel layout and half of the re-pack disappears; Adam is elementwise
     and does not care.  Gradients, exp_avg and exp_avg_sq use the same order (``*_views``)."""
 
-    def __init__(self, params, lr, betas, eps, layouts=None):
+    def __init__(self, params, lr, betas, eps, layouts=None, twin16=False):
+        """``twin16``: keep an fp16 twin of the whole flat parameter buffer, written by the Adam launch itself (fp16-MFMA
+        path: a conv weight whose segment is laid out as the forward GEMM's pack needs no re-pack launch at all -- the
+        fp32 segment IS the pack and ``flat16``'s segment its twin)."""
         self.params = list(params)
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         self.n = n
         self.flat = torch.empty(n, device=dev)
+        self.flat16 = torch.empty(n, dtype=torch.float16, device=dev) if twin16 else None
         self.grad = torch.zeros(n, device=dev)
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
@@ -63,16 +67,24 @@ class FlatGroup:
                 w = view(self.flat)
                 w.copy_(p.detach())
                 p.data = w
+                if self.flat16 is not None:      # the segment's twin, found by chain.packed through the parameter
+                    p._ali_flat16 = self.flat16[off:off + k]
                 gv = view(self.grad)
                 p.grad = gv
                 self.grad_views[id(p)] = gv
                 self.m_views.append(view(self.m))
                 self.v_views.append(view(self.v))
                 off += k
+        self.sync16()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.steps = 0
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side count of completed steps (graph replays)
         self.arrive = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+
+    def sync16(self):
+        """re-round the fp16 twin after the parameters were changed by anything but ``adam`` (load_state, restore)"""
+        if self.flat16 is not None:
+            self.flat16.copy_(self.flat)
 
     @staticmethod
     def logical(views):
@@ -93,7 +105,7 @@ class FlatGroup:
         self.steps += 1
         # the kernel runs step step_t + 1 and its last block advances step_t: no launch for the counter
         ops.adam(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.steps,
-                 dev_step=self.step_t, grad_scale=grad_scale, arrive=self.arrive)
+                 dev_step=self.step_t, grad_scale=grad_scale, arrive=self.arrive, p16=self.flat16)
 
     # torch.optim-like surface for callers that keep the returned optimisers
     def zero_grad(self):
@@ -204,11 +216,13 @@ class AliStepper:
         self.family = family or family_of(E, G, D)
         self.pE, self.pG = get_plan(E.layers), get_plan(G.layers)
         self.pDx, self.pDz, self.pDxz = get_plan(D.dx), get_plan(D.dz), get_plan(D.dxz)
-        # fp32: master weights live in the forward GEMM's layout (FlatGroup.layouts; chain.packed then aliases them).
-        # The fp16 path keeps the re-pack: that launch also writes the fp16 twins the kernels read.
-        lay = _chain.pack_layouts([self.pE, self.pG, self.pDx, self.pDz, self.pDxz]) if precision == "f32" else None
-        self.opt_eg = FlatGroup(list(E.parameters()) + list(G.parameters()), lr, betas, eps, layouts=lay)
-        self.opt_d = FlatGroup(list(D.parameters()), lr, betas, eps, layouts=lay)
+        # Master weights live in the forward GEMM's layout (FlatGroup.layouts; chain.packed then aliases them).  fp16 path:
+        # the Adam launch also writes the fp16 twin of the flat buffer, so the forward packs need no launch either; the
+        # data-gradient packs (transposes) are still re-packed, fp16 twins included.
+        lay = _chain.pack_layouts([self.pE, self.pG, self.pDx, self.pDz, self.pDxz])
+        t16 = precision == "f16" and self.E is not None and next(E.parameters()).is_cuda
+        self.opt_eg = FlatGroup(list(E.parameters()) + list(G.parameters()), lr, betas, eps, layouts=lay, twin16=t16)
+        self.opt_d = FlatGroup(list(D.parameters()), lr, betas, eps, layouts=lay, twin16=t16)
         for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
             pl.cache.store.clear()
             pl.cache.static = True
@@ -676,6 +690,7 @@ class AliStepper:
         for t, v in zip(self._state_tensors(), vals):
             t.copy_(v)
         self.opt_eg.steps, self.opt_d.steps = se, sd
+        self.opt_eg.sync16(), self.opt_d.sync16()
         for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
             pl.cache.refresh()
 
@@ -703,6 +718,7 @@ class AliStepper:
                     vv.zero_()
             group.steps = step
             group.step_t.fill_(step)
+        self.opt_eg.sync16(), self.opt_d.sync16()
         for pl in (self.pE, self.pG, self.pDx, self.pDz, self.pDxz):
             pl.cache.refresh()
 
@@ -740,6 +756,7 @@ class AliStepper:
                     g.steps = int(o["step"])
                 g.step_t.fill_(g.steps)
             self.iter_t.fill_(int(sd.get("iteration", 0)))
+            self.opt_eg.sync16(), self.opt_d.sync16()
             if "dropout_seed" in sd and int(sd["dropout_seed"]) != _dropout._state["seed"]:
                 # the seed is a launch argument of the mask kernel: graphs captured with the old one must go
                 _dropout._state["seed"] = int(sd["dropout_seed"])

@@ -715,7 +715,8 @@ __global__ void bce_logits_kernel(const float* __restrict__ logit, int B, float 
 // step count of a captured graph advances without a launch of its own.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                            int step_host, int* __restrict__ dev_step, int* __restrict__ arrive, float grad_scale) {
+                            int step_host, int* __restrict__ dev_step, int* __restrict__ arrive, float grad_scale,
+                            _Float16* __restrict__ p16) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
   const int t = dev_step ? __hip_atomic_load(dev_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (arrive ? 1 : 0) : step_host;
@@ -730,7 +731,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    const float pn = p[i] - step_size * (mi / denom);
+    p[i] = pn;
+    if (p16) p16[i] = (_Float16)pn;           // fp16 twin of the (kernel-layout) master weights, fp16-MFMA path
   }
   if (arrive) {
     __syncthreads();                   // (every thread of the block has computed with t)
@@ -1400,13 +1403,15 @@ extern "C" int ali_bce_logits_pair(const float* logit, int32_t B, float target_a
 }
 
 extern "C" int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                        float eps, int32_t step, int32_t* dev_step, int32_t* arrive, float grad_scale, ali_stream_t stream) {
+                        float eps, int32_t step, int32_t* dev_step, int32_t* arrive, float grad_scale, void* p16,
+                        ali_stream_t stream) {
   if (!p || !g || !m || !v || n <= 0 || (!dev_step && step < 1) || (arrive && !dev_step)) {
     set_error("ali_adam: bad argument");
     return ALI_ERR_BAD_ARG;
   }
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 4)), dim3(kEwBlock), 0, ST(stream), p, g, m, v, (long long)n, lr, beta1, beta2,
-                     eps, (int)step, reinterpret_cast<int*>(dev_step), reinterpret_cast<int*>(arrive), grad_scale);
+                     eps, (int)step, reinterpret_cast<int*>(dev_step), reinterpret_cast<int*>(arrive), grad_scale,
+                     reinterpret_cast<_Float16*>(p16));
   return check_launch("adam_kernel");
 }
 

@@ -330,9 +330,11 @@ int ali_bce_logits(const float* logit, int32_t B, float target, float gscale, fl
  * dev_step != NULL (graph replays); the gradient is read as grad_scale * g (1/world for DP).
  * With `arrive` (a zeroed device int32 the launch leaves at zero; needs dev_step): *dev_step is the number of COMPLETED
  * steps -- the launch runs step *dev_step + 1 and its last block stores that value back, so a captured graph's step
- * count advances without a launch of its own. */
+ * count advances without a launch of its own.  p16 (optional, n halves): also leave (_Float16)p -- the fp16 twin of
+ * master weights that already live in a GEMM's layout (AliEpilogue.w16), so that no re-pack launch has to produce it. */
 int ali_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-             float eps, int32_t step, int32_t* dev_step, int32_t* arrive, float grad_scale, ali_stream_t stream);
+             float eps, int32_t step, int32_t* dev_step, int32_t* arrive, float grad_scale, void* p16,
+             ali_stream_t stream);
 /* counters[i][0] += incs[i] for n device int64 counters in one launch (nn.BatchNorm2d.num_batches_tracked of every
  * layer, mnist.py:111-123 forward in train mode; the stepper's iteration counter). */
 int ali_add_i64_multi(int32_t n, int64_t* const* counters, const int64_t* incs, ali_stream_t stream);

@@ -413,4 +413,20 @@ def test_fp16_weight_twins_follow_the_optimiser():
                     # ... and the pack itself is the current parameter (spot check through the fp32 pack's norm)
                     assert abs(float(val.double().norm()) - float(param.detach().double().norm())) <= 1e-4 * float(
                         param.detach().double().norm()) or "scatter" in str(key), (capture, key)
-        assert n >= 10
+        assert n >= 6
+        # the forward packs are aliases of the flat master weights (FlatGroup.layouts); their fp16 twin is the flat fp16
+        # buffer the Adam launch writes alongside -- it must equal half(flat) after every step, eager and replayed
+        for grp in (st.opt_eg, st.opt_d):
+            assert grp.flat16 is not None and torch.equal(grp.flat16, grp.flat.half()), capture
+        with ops.precision("f16"):
+            k = 0
+            for plan in (st.pE, st.pG, st.pDx, st.pDz, st.pDxz):
+                for stg in plan.stages[1:]:
+                    if stg.kind in ("conv", "convT") and stg.mod.weight.dim() == 4:
+                        cin = stg.mod.weight.shape[1] if stg.kind == "conv" else stg.mod.weight.shape[0]
+                        wp = plan.packed(stg, "fwd", cin)
+                        h = ops.shadow16(wp)
+                        if h is not None and wp.data_ptr() == stg.mod.weight.data_ptr():
+                            k += 1
+                            assert torch.equal(h, wp.half()), (capture, stg.index)
+            assert k >= 8
