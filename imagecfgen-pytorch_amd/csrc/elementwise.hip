@@ -41,16 +41,56 @@ struct PackJob {
   const float* src; float* dst; _Float16* dst16;
   int N, T, C, Cpad; long long s_n, s_tap, s_c;
   int blk0;
-  int tiled;                       // 1: batched transpose below
+  int tiled;                       // 1: batched transpose below (32 x 32 tiles); 2: 64 x 64 tiles, 16-byte accesses
   int batch, I, J, Ipad, ti, tj;   // tiles per batch entry: ti x tj
-  long long in_b, in_i, out_b;     // in[b*in_b + i*in_i + j], out[b*out_b + j*Ipad + i]
+  long long in_b, in_i, out_b;     // in[b*in_b + i*in_i + j], out[b*out_b + j*out_j + i]   (out_j = Ipad for tiled == 1)
+  long long out_j;
 };
 struct PackJobs { PackJob j[40]; int n; };
 __global__ void __launch_bounds__(256) pack_weights_multi_kernel(PackJobs jobs) {
   __shared__ float tile[32][33];
+  __shared__ float tile64[64][65];
   int k = 0;
   while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].blk0) ++k;
   const PackJob& J = jobs.j[k];
+  if (J.tiled == 2) {
+    // 64 x 64 tile, 16-byte loads along j (contiguous in the source) and 16-byte stores along i (contiguous in the
+    // destination), 16 KB in flight per block: the data-gradient pack [C][T][K] of a master weight kept in the forward
+    // pack's order [K][T][C] (FlatGroup.layouts) is, per tap, such a transpose (the element-wise form read it with a
+    // stride of T*C floats from 256 blocks: 1 TB/s on the 7 GB of ESRF weights).
+    int rel = (int)blockIdx.x - J.blk0;
+    const int per = J.ti * J.tj;
+    const int b = rel / per;
+    rel -= b * per;
+    const int it = rel / J.tj, jt = rel - it * J.tj;
+    const int i0 = it * 64, j0 = jt * 64;
+    const float* in = J.src + (long long)b * J.in_b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = threadIdx.x + 256 * q, r = idx >> 4, c4 = idx & 15;
+      const int i = i0 + r, j = j0 + 4 * c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < J.I && j < J.J) v = *reinterpret_cast<const f32x4*>(in + (long long)i * J.in_i + j);
+      tile64[r][4 * c4 + 0] = v[0]; tile64[r][4 * c4 + 1] = v[1]; tile64[r][4 * c4 + 2] = v[2]; tile64[r][4 * c4 + 3] = v[3];
+    }
+    __syncthreads();
+    float* out = J.dst + (long long)b * J.out_b;
+    _Float16* out16 = J.dst16 ? J.dst16 + (long long)b * J.out_b : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = threadIdx.x + 256 * q, r = idx >> 4, c4 = idx & 15;
+      const int j = j0 + r, i = i0 + 4 * c4;
+      if (j < J.J && i < J.Ipad) {
+        const f32x4 v = {tile64[4 * c4 + 0][r], tile64[4 * c4 + 1][r], tile64[4 * c4 + 2][r], tile64[4 * c4 + 3][r]};
+        *reinterpret_cast<f32x4*>(out + (long long)j * J.out_j + i) = v;
+        if (out16) {
+          using h4 = __attribute__((ext_vector_type(4))) _Float16;
+          *reinterpret_cast<h4*>(out16 + (long long)j * J.out_j + i) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+      }
+    }
+    return;
+  }
   if (J.tiled) {
     int rel = (int)blockIdx.x - J.blk0;
     const int per = J.ti * J.tj;
@@ -1011,8 +1051,18 @@ extern "C" int ali_pack_weights_multi(int32_t n_jobs, const float* const* src, f
     } else if (J.T >= 1 && J.s_tap == 1 && J.s_n == J.T && J.s_c == NT && NT < (1LL << 31) && NT >= 64) {
       J.tiled = 1; J.batch = 1; J.I = J.C; J.J = (int)NT; J.in_b = 0; J.in_i = NT; J.out_b = 0;
     }
-    if (J.tiled) {
+    // master weights in the forward pack's order (contiguous n, FlatGroup.layouts): per tap a [C] x [N] transpose
+    const bool al16 = ((((unsigned long long)J.src) | ((unsigned long long)J.dst)) & 15ull) == 0 &&
+                      (!J.dst16 || (((unsigned long long)J.dst16) & 7ull) == 0);
+    if (!J.tiled && J.s_n == 1 && (J.N % 4) == 0 && (J.Cpad % 4) == 0 && (J.s_tap % 4) == 0 && (J.s_c % 4) == 0 && al16 &&
+        NT * J.Cpad >= (1LL << 18) && J.N >= 32 && J.C >= 32) {
+      J.tiled = 2; J.batch = J.T; J.I = J.C; J.J = J.N; J.Ipad = J.Cpad;
+      J.in_b = J.s_tap; J.in_i = J.s_c; J.out_b = J.Cpad; J.out_j = (long long)J.T * J.Cpad;
+      J.ti = (J.Ipad + 63) / 64; J.tj = (J.J + 63) / 64;
+      blk += (long long)J.batch * J.ti * J.tj;
+    } else if (J.tiled) {
       J.Ipad = J.Cpad;
+      J.out_j = J.Ipad;
       J.ti = (J.Ipad + 31) / 32; J.tj = (J.J + 31) / 32;
       blk += (long long)J.batch * J.ti * J.tj;
     } else {
