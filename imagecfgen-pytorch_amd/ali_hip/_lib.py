@@ -53,6 +53,7 @@ SIGNATURES = {
     "ali_conv_workspace_bytes": (c_size_t, [POINTER(AliConvGeom), c_int32]),
     "ali_conv_mtiles": (c_int32, [POINTER(AliConvGeom), c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "ali_conv_writes_out16": (c_int32, [POINTER(AliConvGeom), c_int32]),
+    "ali_conv_uses_f16": (c_int32, [POINTER(AliConvGeom), c_int32, POINTER(AliEpilogue)]),
     "ali_conv_tile_order": (c_int32, [POINTER(AliConvGeom), c_int32, c_int32, c_void_p, c_int32]),
     "ali_conv_fwd": (c_int32, [POINTER(AliConvGeom), c_void_p, c_void_p, c_void_p, POINTER(AliEpilogue), c_void_p,
                                c_size_t, c_void_p]),
@@ -110,6 +111,8 @@ SIGNATURES = {
     "ali_plane_table_grad": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "ali_col2im": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 12 + [c_float, c_void_p]),
+    "ali_tconv_scatter_ok": (c_int32, [c_int32] * 5),
+    "ali_tconv_scatter": (c_int32, [c_void_p] * 4 + [c_int32] * 13 + [c_float, c_void_p]),
     "ali_tconv1_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_float, c_void_p, c_int32,
                                                                                             c_void_p]),
     "ali_tconv1_dgrad": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p] + [c_int32] * 7

@@ -558,13 +558,18 @@ def chain_forward_gen(plan: ChainPlan, x: torch.Tensor, training: bool, c_log_in
             m = st.mod
             R, S = m.kernel_size
             Co = m.out_channels
-            contrib = (alloc(("contrib", si), (B, H, W, Co * R * S)) if alloc is not None
-                       else torch.empty(B, H, W, Co * R * S, dtype=torch.float32, device=cur.device))
-            ops.conv_fwd(ops.geom(B, H, W, Cp, H, W, Co * R * S, 1, 1, 1, 0), t, plan.packed(st, "scatter", Cp), contrib,
-                         ops.epilogue(), live=(c_log, None))
-            yield
-            ops.col2im(contrib, Co * R * S, plan.packed_bias(st), y, B, H, W, out_shape[1], out_shape[2], Co, Co, R, S,
-                       m.stride[0], m.padding[0], st.act, st.slope)
+            if ops.tconv_scatter_ok(Cp, Co, R, S, m.stride[0]) and t.is_contiguous():
+                # contributions kept in LDS per output tile: one launch, no [pixels][taps] tensor
+                ops.tconv_scatter(t, plan.packed(st, "scatter", Cp), plan.packed_bias(st), y, B, H, W, Cp, out_shape[1],
+                                  out_shape[2], Co, Co, R, S, m.stride[0], m.padding[0], st.act, st.slope)
+            else:
+                contrib = (alloc(("contrib", si), (B, H, W, Co * R * S)) if alloc is not None
+                           else torch.empty(B, H, W, Co * R * S, dtype=torch.float32, device=cur.device))
+                ops.conv_fwd(ops.geom(B, H, W, Cp, H, W, Co * R * S, 1, 1, 1, 0), t, plan.packed(st, "scatter", Cp),
+                             contrib, ops.epilogue(), live=(c_log, None))
+                yield
+                ops.col2im(contrib, Co * R * S, plan.packed_bias(st), y, B, H, W, out_shape[1], out_shape[2], Co, Co, R,
+                           S, m.stride[0], m.padding[0], st.act, st.slope)
         elif _is_tconv1(st, Cp):
             m = st.mod
             ops.tconv1_fwd(t, plan.packed(st, "fwd", Cp), plan.packed_bias(st), y, B, H, W, Cp, m.kernel_size[0],
@@ -693,6 +698,15 @@ def chain_backward_gen(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, 
         if i == 0 and sv.bn is None and _scatter_dgrad(st, gx_planes):
             R, S = m.kernel_size
             NP = len(gx_planes)
+            if ops.tconv_scatter_ok(K, NP, R, S, m.stride[0]) and g_pre.is_contiguous():
+                planes = torch.empty(B, H, W, NP, dtype=torch.float32, device=gy.device)
+                ops.tconv_scatter(g_pre, plan.packed(st, ("scatter_dgrad", tuple(gx_planes)), Cp), None, planes, B, P, Q, K,
+                                  H, W, NP, NP, R, S, m.stride[0], m.padding[0])
+                if sv.mask is not None:
+                    cols = torch.cat([sv.mask[:, c:c + 1] for c in gx_planes], dim=1)
+                    planes = planes * cols.reshape(B, 1, 1, -1)
+                gx = planes
+                break
             contrib = torch.empty(B, P, Q, NP * R * S, dtype=torch.float32, device=gy.device)
             ops.conv_fwd(ops.geom(B, P, Q, K, P, Q, NP * R * S, 1, 1, 1, 0), g_pre,
                          plan.packed(st, ("scatter_dgrad", tuple(gx_planes)), Cp), contrib, ops.epilogue())

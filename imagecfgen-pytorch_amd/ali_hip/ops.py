@@ -251,7 +251,8 @@ _HOOK = None
 
 class launch_hook:
     """``with ops.launch_hook(obj):`` -- tests only.  Every GEMM launch made inside the block is reported to ``obj``
-    right after it has been issued: ``obj.gemm(kind, g, a, w, out, ep, in_ld, out_ld)`` for ``conv_fwd`` ("fwd") /
+    right after it has been issued (``obj.scatter(...)`` for ``tconv_scatter``):
+    ``obj.gemm(kind, g, a, w, out, ep, in_ld, out_ld)`` for ``conv_fwd`` ("fwd") /
     ``conv_bwd_data`` ("bwd_data") and ``obj.wgrad(g, x, dy, dst, cg_log, cd_log, strides, db, dy_ld)`` for
     ``conv_bwd_weight`` -- the latter returns a callable (or None) that is run once the result is final (at once, or
     after ``FoldQueue.flush`` for deferred launches).  tests/launch_audit.py re-computes each launch with torch on the
@@ -927,6 +928,24 @@ def col2im(contrib, ldc, bias, out, B, H, W, Hout, Wout, NC, ostride, R, S, stri
     lib = _lib.load()
     _lib.check(lib.ali_col2im(_chk(contrib, "contrib"), ldc, _opt(bias, "bias"), _chk(out, "out"), B, H, W, Hout, Wout,
                               NC, ostride, R, S, stride, pad, act, float(slope), _stream()), "ali_col2im")
+    return out
+
+
+def tconv_scatter_ok(C, NC, R, S, stride):
+    return bool(_lib.load().ali_tconv_scatter_ok(C, NC, R, S, stride))
+
+
+def tconv_scatter(x, w_nc, bias, out, B, H, W, C, Hout, Wout, NC, ostride, R, S, stride, pad, act=ACT_NONE, slope=0.0):
+    """Scatter-form transposed convolution to 1-2 channels in one launch (include/ali_hip.h: ali_tconv_scatter)."""
+    lib = _lib.load()
+
+    def go():
+        _lib.check(lib.ali_tconv_scatter(_chk(x, "x"), _chk(w_nc, "w"), _opt(bias, "bias"), _ptr(out), B, H, W, C, Hout,
+                                         Wout, NC, ostride, R, S, stride, pad, act, float(slope), _stream()),
+                   "ali_tconv_scatter")
+    _launch("tconv_scatter", (2.0 * B * H * W * C * NC * R * S, 4.0 * B * (H * W * C + Hout * Wout * NC), _NO_SHAPE), go)
+    if _HOOK is not None and hasattr(_HOOK, "scatter"):
+        _HOOK.scatter(x, w_nc, bias, out, (B, H, W, C, Hout, Wout, NC, ostride, R, S, stride, pad), act, slope)
     return out
 
 

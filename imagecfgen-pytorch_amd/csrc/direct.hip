@@ -225,6 +225,128 @@ __global__ __launch_bounds__(64 * NW) void tconv1_fwd_mfma_kernel(const T1Desc d
   }
 }
 
+// ---------------------------------------------------------------- transposed convolution to 1-2 channels, any stride
+// The Generator tails of the spectrogram stacks (ConvTranspose2d(64 -> 1, 5, stride 2, pad 2, out_pad 1) on 64^2 ... 256^2
+// maps, audio_mnist.py:243 and its whalecalls / esrf_acoustic copies) and the consumed input plane of their first
+// Conv2d's data gradient (audio_mnist.py:186).  They used to be a 1x1 GEMM with N = taps columns writing a
+// [pixels][taps] contribution tensor plus ali_col2im reading it back: 100 B per input pixel each way, 0.77 ms per ESRF
+// launch for 0.25 ms of input.  Here the contributions never leave the CU -- the scatter form of tconv1_fwd_mfma_kernel,
+// tiled: a block owns OBH x OBW output pixels of one image, multiplies the (OBH / stride + halo) x (OBW / stride + halo)
+// input pixels that reach them by the [64 x N] tap matrix on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32;
+// operand layout as above), keeps the products in LDS ([pixels][LDC]), and every output pixel then sums its taps in
+// ali_col2im's order.  HBM traffic = the input once (+ ~20 % halo, mostly L2 hits) + the 1-2 channel output.
+struct TSDesc {
+  const float* x; const float* w; const float* bias; float* out;
+  int B, H, W, Hout, Wout, NC, ostride, R, S, stride, pad, act; float slope;
+  int OBH, OBW, ntx, N, LDC;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void tconv_scatter_kernel(const TSDesc d) {
+  constexpr int KC = 4, NW = 4, K = 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* contrib = smem;                                  // [nh * nw][LDC]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / d.ntx, tx = blockIdx.x - ty * d.ntx;
+  const int o0 = ty * d.OBH, c0 = tx * d.OBW;
+  const int st = d.stride, pad = d.pad, LDC = d.LDC, N = d.N;
+  // input pixels that reach this tile: ih * st - pad + r in [o0, o0 + OBH) for some tap r
+  auto lo = [&](int o, int taps) { const int v = o + pad - (taps - 1); return v <= 0 ? 0 : (v + st - 1) / st; };
+  const int ih_lo = lo(o0, d.R), iw_lo = lo(c0, d.S);
+  const int ih_hi = min(d.H - 1, (min(o0 + d.OBH, d.Hout) - 1 + pad) / st);
+  const int iw_hi = min(d.W - 1, (min(c0 + d.OBW, d.Wout) - 1 + pad) / st);
+  const int nh = max(ih_hi - ih_lo + 1, 0), nw = max(iw_hi - iw_lo + 1, 0);
+  const int npx = nh * nw;
+  const int m = lane & 15, kq = lane >> 4;
+  // weights: wreg[nt][j][e] = w[column n = 16 nt + m][channel 16 j + 4 kq + e]   (columns >= N: 0)
+  float wreg[NT][KC][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + m;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if (n < N) v = *reinterpret_cast<const f32x4v*>(d.w + (long long)n * K + 16 * j + 4 * kq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wreg[nt][j][e] = v[e];
+    }
+  }
+  const float* src = d.x + ((long long)(b * d.H + ih_lo) * d.W + iw_lo) * K + 4 * kq;
+  const int ntile = (npx + 15) >> 4;
+  const float rnw = 1.0f / (float)max(nw, 1);
+  auto load_tile = [&](int tile, f32x4v (&a)[KC]) {
+    const int pix = tile * 16 + m;
+    const bool ok = tile < ntile && pix < npx;
+    int r = (int)((float)pix * rnw);                      // pix / nw, corrected: pix < 2^16
+    r -= (r * nw > pix);
+    r += ((r + 1) * nw <= pix);
+    const int c = pix - r * nw;
+    const float* p = src + ((long long)r * d.W + c) * K;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      a[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (ok) a[j] = *reinterpret_cast<const f32x4v*>(p + 16 * j);       // (a tile may have no input pixel at all)
+    }
+  };
+  auto compute_tile = [&](int tile, const f32x4v (&a)[KC]) {
+    f32x4v acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][e], wreg[nt][j][e], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + m;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pix = tile * 16 + 4 * kq + i;
+        if (n < N && pix < npx) contrib[pix * LDC + n] = acc[nt][i];
+      }
+    }
+  };
+  f32x4v a0[KC], a1[KC], a2[KC];
+  load_tile(wave, a0);
+  load_tile(wave + NW, a1);
+  load_tile(wave + 2 * NW, a2);
+  for (int tile = wave; tile < ntile; tile += 3 * NW) {
+    compute_tile(tile, a0);
+    load_tile(tile + 3 * NW, a0);
+    if (tile + NW < ntile) compute_tile(tile + NW, a1);
+    load_tile(tile + 4 * NW, a1);
+    if (tile + 2 * NW < ntile) compute_tile(tile + 2 * NW, a2);
+    load_tile(tile + 5 * NW, a2);
+  }
+  __syncthreads();
+  const int NC = d.NC;
+  const int obw_shift = 31 - __builtin_clz(d.OBW);        // OBW is a power of two
+  for (int o = t; o < d.OBH * d.OBW; o += 256) {
+    const int oy = o0 + (o >> obw_shift), ox = c0 + (o & (d.OBW - 1));
+    if (oy >= d.Hout || ox >= d.Wout) continue;
+    float acc0 = d.bias ? d.bias[0] : 0.f, acc1 = (d.bias && NC > 1) ? d.bias[1] : 0.f;
+    const int r0 = (oy + pad) % st, s0 = (ox + pad) % st;
+    for (int r = r0; r < d.R; r += st) {
+      const int ih = (oy + pad - r) / st;
+      if (oy + pad - r < 0 || ih >= d.H) continue;
+      for (int sx = s0; sx < d.S; sx += st) {
+        const int iw = (ox + pad - sx) / st;
+        if (ox + pad - sx < 0 || iw >= d.W) continue;
+        const float* cp = contrib + ((ih - ih_lo) * nw + (iw - iw_lo)) * LDC + (r * d.S + sx) * NC;
+        acc0 += cp[0];
+        if (NC > 1) acc1 += cp[1];
+      }
+    }
+    float* op = d.out + ((long long)(b * d.Hout + oy) * d.Wout + ox) * d.ostride;
+    op[0] = apply_act(acc0, d.act, d.slope);
+    if (NC > 1) op[1] = apply_act(acc1, d.act, d.slope);
+  }
+}
+
 // ---------------------------------------------------------------- data gradient: small (1 ch) -> big (K ch)
 // One thread owns 4 channels (k4 = thread % (K/4): the grid stride is a multiple of K/4) and keeps their filter taps in
 // registers (TAPS x 4 floats), so an output costs TAPS scalar reads of the 1-channel map and 4*TAPS fma -- no LDS traffic
@@ -569,6 +691,49 @@ extern "C" int ali_tconv1_fwd(const float* big, const float* w_tk, const float* 
   else T1F(1, 1);
 #undef T1F
   return check_launch("tconv1_fwd_kernel");
+}
+
+extern "C" int32_t ali_tconv_scatter_ok(int32_t C, int32_t NC, int32_t R, int32_t S, int32_t stride) {
+  return (C == 64 && NC >= 1 && NC <= 2 && R >= 1 && S >= 1 && R <= 8 && S <= 8 && NC * R * S <= 64 && stride >= 1 &&
+          stride <= 4 && tuning().no_t1_mfma == 0) ? 1 : 0;      // (ALI_NO_T1_MFMA=1: the two-launch form, A/B)
+}
+
+extern "C" int ali_tconv_scatter(const float* x, const float* w_nc, const float* bias, float* out, int32_t B, int32_t H,
+                                 int32_t W, int32_t C, int32_t Hout, int32_t Wout, int32_t NC, int32_t ostride, int32_t R,
+                                 int32_t S, int32_t stride, int32_t pad, int32_t act, float slope, ali_stream_t stream) {
+  if (!x || !w_nc || !out || B <= 0 || B > 65535 || H <= 0 || W <= 0 || Hout <= 0 || Wout <= 0 || ostride < NC || pad < 0 ||
+      !ali_tconv_scatter_ok(C, NC, R, S, stride)) {
+    set_error("ali_tconv_scatter: bad argument (needs 64 input channels, 1-2 output channels, <= 64 tap columns)");
+    return ALI_ERR_BAD_ARG;
+  }
+  TSDesc d = {};
+  d.x = x; d.w = w_nc; d.bias = bias; d.out = out;
+  d.B = B; d.H = H; d.W = W; d.Hout = Hout; d.Wout = Wout; d.NC = NC; d.ostride = ostride; d.R = R; d.S = S;
+  d.stride = stride; d.pad = pad; d.act = act; d.slope = slope;
+  d.N = NC * R * S;
+  d.LDC = d.N | 1;
+  // output tile: as large as 64 KB of contributions allow (two blocks per CU), at most 32 x 64
+  int obh = 32, obw = 64;
+  auto npx = [&](int bh, int bw) {
+    return (long long)((bh - 1 + R - 1) / stride + 1) * ((bw - 1 + S - 1) / stride + 1);
+  };
+  while (npx(obh, obw) * d.LDC * 4 > 64 * 1024 && (obh > 4 || obw > 8)) {
+    if (obw > 2 * obh && obw > 8) obw >>= 1; else if (obh > 4) obh >>= 1; else obw >>= 1;
+  }
+  if (npx(obh, obw) * d.LDC * 4 > 64 * 1024 || npx(obh, obw) >= 65536) { set_error("ali_tconv_scatter: filter too large"); return ALI_ERR_BAD_ARG; }
+  d.OBH = obh; d.OBW = obw;
+  d.ntx = (Wout + obw - 1) / obw;
+  const long long nblk = (long long)d.ntx * ((Hout + obh - 1) / obh);
+  if (nblk >= (1LL << 31)) { set_error("ali_tconv_scatter: output too large"); return ALI_ERR_BAD_ARG; }
+  const size_t lds = (size_t)npx(obh, obw) * d.LDC * sizeof(float);
+  dim3 grid((unsigned)nblk, B);
+#define TSC(NT_) hipLaunchKernelGGL((tconv_scatter_kernel<NT_>), grid, dim3(256), lds, (hipStream_t)stream, d)
+  if (d.N <= 16) TSC(1);
+  else if (d.N <= 32) TSC(2);
+  else if (d.N <= 48) TSC(3);
+  else TSC(4);
+#undef TSC
+  return check_launch("tconv_scatter_kernel");
 }
 
 extern "C" int ali_tconv1_dgrad(const float* small, int32_t sstride, const float* w_tk, const float* dact_y,

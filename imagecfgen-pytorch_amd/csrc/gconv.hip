@@ -970,7 +970,7 @@ struct TileCfg { int bm, bn; };
 // fp32 MFMA cannot overlap with VALU work of the same SIMD, and a lone wave per SIMD cannot hide its barrier / memory
 // waits: prefer the largest tile that still gives every CU two resident blocks (>= 512 blocks), measured best on the
 // MorphoMNIST layer shapes at bs=512 (scratch/mb3.py).
-static TileCfg pick_tile(long long M, int N, bool f16) {
+static TileCfg pick_tile(long long M, int N, bool f16, int cin) {
   TileCfg best = {64, 64};
   if (N <= 32) { best.bm = 128; best.bn = 32; return best; }
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (long long)((N + bn - 1) / bn); };
@@ -986,6 +986,9 @@ static TileCfg pick_tile(long long M, int N, bool f16) {
     // cycles -- the register-staged LDS fill is the limit; the fix is LDS-DMA staging, not tile area.
     if (N > 64 && blocks(128, 128) >= kNumCU / 2) { best.bm = 128; best.bn = 128; return best; }
     if (N > 64 && blocks(64, 128) >= kNumCU / 2) { best.bm = 64; best.bn = 128; return best; }
+    // (64-channel outputs, e.g. the data gradient of the stacks' second conv, 1.6 M rows x 64 <- 128 x 25 at 330 TF/s:
+    // a 192 x 64 tile -- 256 staged rows per k-tile like 128 x 128, two blocks per CU -- won 10 % stand-alone
+    // (scratch/mb_dgrad16.py) and lost 17 % inside the iteration, 256 x 64 with one block per CU lost 50 %: dropped)
     return best;
   }
   // measured (scratch/mb3.py): 64x64 (4 resident blocks per CU) wins or ties up to a few thousand blocks;
@@ -1005,7 +1008,8 @@ static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps) {
     if (d.ph[i].nr * d.ph[i].ns > max_taps) max_taps = d.ph[i].nr * d.ph[i].ns;
     if (d.ph[i].M >= (1 << 24)) { set_error("gconv: more than 2^24 rows in one phase"); return -1; }
   }
-  tc = pick_tile(Mtot * (tuning().tile_m_scale > 0 ? tuning().tile_m_scale : 1), d.Cout, d.f16 && vec && (d.Cin % BK) == 0);
+  const bool f16_loop = d.f16 && vec && (d.Cin % BK) == 0;
+  tc = pick_tile(Mtot * (tuning().tile_m_scale > 0 ? tuning().tile_m_scale : 1), d.Cout, f16_loop, d.Cin);
   if (tuning().bm > 0 && tuning().bn > 0) { tc.bm = tuning().bm; tc.bn = tuning().bn; }
   if (!vec && tc.bn == 128) tc.bn = 64;
   int tiles = 0;
@@ -1193,7 +1197,8 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     else if (vec) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 1>), grid, block, 0, stream, d); \
     else hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 0>), grid, block, 0, stream, d);          \
   } while (0)
-  if (tc.bm == 128 && tc.bn == 128) LAUNCH(128, 128, 2, 2);
+  if (tc.bm > 128 || tc.bn > 128) { set_error("gconv: no kernel for this tile"); return ALI_ERR_BAD_ARG; }
+  else if (tc.bm == 128 && tc.bn == 128) LAUNCH(128, 128, 2, 2);
   else if (tc.bm == 128 && tc.bn == 64) LAUNCH(128, 64, 2, 2);
   else if (tc.bm == 128 && tc.bn == 32) LAUNCH(128, 32, 4, 1);
   else if (tc.bm == 64 && tc.bn == 128) LAUNCH(64, 128, 2, 2);
@@ -1396,17 +1401,40 @@ struct S2Desc {
   unsigned in_bytes;
 };
 
-template <int C>
+template <int C, bool F16>
 __global__ __launch_bounds__(256) void conv_s2_first_kernel(const S2Desc d) {
   constexpr int T = 25, K = 64;
-  constexpr int NP = C == 4 ? 13 : 25;                 // k-slot pairs: C = 4 (tap 2j | tap 2j+1), C = 8 (lo | hi half of tap j)
-  constexpr int LDW = T * C + (C == 8 ? 4 : 0);        // LDS row pitch: ds_read_b128 of 16 consecutive n conflict-free
-  extern __shared__ __attribute__((aligned(16))) float s2_w[];   // [64][LDW]
+  // fp32: k-slot pairs -- C = 4 (tap 2j | tap 2j+1), C = 8 (lo | hi half of tap j), one v_mfma_f32_32x32x2_f32 per channel
+  // F16 (precision "f16" launches): groups of 16 k-slots = one v_mfma_f32_32x32x16_f16 -- C = 4: taps 4j .. 4j+3, the
+  //      half-wave h holds taps 4j+2h, 4j+2h+1; C = 8: taps 2j, 2j+1, half-wave h holds tap 2j+h.  Operands rounded to
+  //      fp16 (RNE) in registers / on their way into LDS, fp32 accumulation: the arithmetic of the fp16 GEMM loop.
+  constexpr int NP = F16 ? (C == 4 ? 7 : 13) : (C == 4 ? 13 : 25);
+  constexpr int NBATCH = F16 ? NP : 13;                 // gathers in flight per lane: F16 2 per group, fp32 1 per pair
+  constexpr int TPAD = F16 ? (C == 4 ? 28 : 26) : T;    // taps per weight row in LDS (dead taps hold zeros)
+  // LDS row pitch: ds_read_b128 of 16 consecutive n conflict-free (fp32: 100 / 204 floats; fp16: 120 / 216 halves)
+  constexpr int LDW = F16 ? TPAD * C + 8 : T * C + (C == 8 ? 4 : 0);
+  extern __shared__ __attribute__((aligned(16))) float s2_w[];   // fp32 [64][LDW] floats, F16 [64][LDW] halves
+  _Float16* s2_h = reinterpret_cast<_Float16*>(s2_w);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < K * T * C / 4; i += 256) {
-    const int n = i / (T * C / 4), rem = i - n * (T * C / 4);
-    *reinterpret_cast<f32x4*>(s2_w + n * LDW + rem * 4) = *reinterpret_cast<const f32x4*>(d.w + (long long)n * T * C + rem * 4);
+  if (F16) {
+    for (int i = t; i < K * TPAD * C / 4; i += 256) {
+      const int n = i / (TPAD * C / 4), rem = i - n * (TPAD * C / 4);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rem * 4 < T * C) v = *reinterpret_cast<const f32x4*>(d.w + (long long)n * T * C + rem * 4);
+      f16x4 hv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
+      *reinterpret_cast<f16x4*>(s2_h + ((n >> 1) + 32 * (n & 1)) * LDW + rem * 4) = hv;
+    }
+  } else {
+    for (int i = t; i < K * T * C / 4; i += 256) {
+      const int n = i / (T * C / 4), rem = i - n * (T * C / 4);
+      *reinterpret_cast<f32x4*>(s2_w + ((n >> 1) + 32 * (n & 1)) * LDW + rem * 4) =
+          *reinterpret_cast<const f32x4*>(d.w + (long long)n * T * C + rem * 4);
+    }
   }
+  // (LDS row m holds channel 2m, row 32 + m channel 2m + 1: a lane then owns two NEIGHBOURING channels of its pixels and
+  // a store instruction writes whole 256-byte pixel rows -- 128-byte runs of the fp16 twin)
   __syncthreads();
   const int m = lane & 31, h = lane >> 5;
   const int prow = blockIdx.x * 4 + wave;               // this wave's output row (all waves stay for the barrier above)
@@ -1414,7 +1442,7 @@ __global__ __launch_bounds__(256) void conv_s2_first_kernel(const S2Desc d) {
   if (prow >= d.P) return;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)d.in, 0, d.in_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
-  const float bias0 = d.bias ? d.bias[m] : 0.f, bias1 = d.bias ? d.bias[32 + m] : 0.f;
+  const float bias0 = d.bias ? d.bias[2 * m] : 0.f, bias1 = d.bias ? d.bias[2 * m + 1] : 0.f;
   const int ih0 = prow * 2 - d.pad;
   float* orow = d.out + ((long long)(b * d.P + prow) * d.Q) * K;
   _Float16* orow16 = d.out16 ? d.out16 + ((long long)(b * d.P + prow) * d.Q) * K : nullptr;
@@ -1423,51 +1451,74 @@ __global__ __launch_bounds__(256) void conv_s2_first_kernel(const S2Desc d) {
     const int iw0 = q * 2 - d.pad;
     int wsel = 0;
     asm volatile("" : "+v"(wsel));     // (keeps the weight fragments' LDS reads inside the loop: hoisted, they cost 100-200 VGPRs)
-    const float* wl = s2_w + m * LDW + wsel;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    // two batches of pairs: at most 13 gathers in flight per lane
+    auto gather = [&](int tap, int choff) -> f32x4 {
+      const int r = tap / 5, sx = tap - r * 5;
+      const int ih = ih0 + r, iw = iw0 + sx;
+      const bool ok = tap < T && q < d.Q && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+      const unsigned off = ok ? (unsigned)((((b * d.H + ih) * d.W + iw) * C + choff) * 4) : OOB;
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0));
+    };
+    if constexpr (F16) {
+      const _Float16* wl = s2_h + m * LDW + wsel;
+      f32x4 a[NP][2];
 #pragma unroll
-    for (int j0 = 0; j0 < NP; j0 += 13) {
-      f32x4 a[13];
-#pragma unroll
-      for (int jj = 0; jj < 13; ++jj) {
-        const int j = j0 + jj;
-        if (j >= NP) break;
-        const int tap = C == 4 ? 2 * j + h : j;
-        const int r = tap / 5, sx = tap - r * 5;
-        const int ih = ih0 + r, iw = iw0 + sx;
-        const bool ok = tap < T && q < d.Q && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-        const unsigned off = ok ? (unsigned)((((b * d.H + ih) * d.W + iw) * C + (C == 8 ? 4 * h : 0)) * 4) : OOB;
-        a[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (int)off, 0, 0));
+      for (int j = 0; j < NP; ++j) {
+        if (C == 4) { a[j][0] = gather(4 * j + 2 * h, 0); a[j][1] = gather(4 * j + 2 * h + 1, 0); }
+        else { a[j][0] = gather(2 * j + h, 0); a[j][1] = gather(2 * j + h, 4); }
       }
 #pragma unroll
-      for (int jj = 0; jj < 13; ++jj) {
-        const int j = j0 + jj;
-        if (j >= NP) break;
-        const int tap = C == 4 ? 2 * j + h : j;
-        const int woff = (tap < T ? tap : 0) * C + (C == 8 ? 4 * h : 0);
-        f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + woff);
-        f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + 32 * LDW + woff);
-        if (tap >= T) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
+      for (int j = 0; j < NP; ++j) {
+        f16x8 ha;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj][e], w0[e], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj][e], w1[e], acc1, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) { ha[e] = (_Float16)a[j][0][e]; ha[4 + e] = (_Float16)a[j][1][e]; }
+        const f16x8 w0 = *reinterpret_cast<const f16x8*>(wl + 16 * j + 8 * h);
+        const f16x8 w1 = *reinterpret_cast<const f16x8*>(wl + 32 * LDW + 16 * j + 8 * h);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, w1, acc1, 0, 0, 0);
+      }
+    } else {
+      const float* wl = s2_w + m * LDW + wsel;
+      // two batches of pairs: at most 13 gathers in flight per lane
+#pragma unroll
+      for (int j0 = 0; j0 < NP; j0 += NBATCH) {
+        f32x4 a[NBATCH];
+#pragma unroll
+        for (int jj = 0; jj < NBATCH; ++jj) {
+          const int j = j0 + jj;
+          if (j >= NP) break;
+          a[jj] = gather(C == 4 ? 2 * j + h : j, C == 8 ? 4 * h : 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < NBATCH; ++jj) {
+          const int j = j0 + jj;
+          if (j >= NP) break;
+          const int tap = C == 4 ? 2 * j + h : j;
+          const int woff = (tap < T ? tap : 0) * C + (C == 8 ? 4 * h : 0);
+          f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + woff);
+          f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + 32 * LDW + woff);
+          if (tap >= T) { w0 = f32x4{0.f, 0.f, 0.f, 0.f}; w1 = w0; }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj][e], w0[e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj][e], w1[e], acc1, 0, 0, 0);
+          }
         }
       }
     }
-    // acc(row = pixel (r&3) + 8*(r>>2) + 4*(lane>>5), col = channel lane&31): a store instruction writes two full
-    // 128-byte runs (measured against 16-byte stores of 4 channels per lane, which touch half a sector each: 732 vs 785 us)
+    // acc0 / acc1 (row = pixel (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31) = channels 2m / 2m+1 of that pixel
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qq = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (qq < d.Q) {
         const float v0 = apply_act(acc0[r] + bias0, d.act, d.slope), v1 = apply_act(acc1[r] + bias1, d.act, d.slope);
-        orow[(long long)qq * K + m] = v0;
-        orow[(long long)qq * K + 32 + m] = v1;
-        if (orow16) { orow16[(long long)qq * K + m] = (_Float16)v0; orow16[(long long)qq * K + 32 + m] = (_Float16)v1; }
+        *reinterpret_cast<float2*>(orow + (long long)qq * K + 2 * m) = float2{v0, v1};
+        if (orow16) {
+          using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+          *reinterpret_cast<f16x2*>(orow16 + (long long)qq * K + 2 * m) = f16x2{(_Float16)v0, (_Float16)v1};
+        }
       }
     }
   }
@@ -1491,8 +1542,11 @@ static int conv_s2_first_launch(const AliConvGeom* g, const float* x, const floa
   d.B = g->B; d.H = g->H; d.W = g->W; d.P = g->P; d.Q = g->Q; d.pad = g->pad;
   d.in_bytes = (unsigned)((long long)g->B * g->H * g->W * g->C * 4);
   dim3 grid((g->P + 3) / 4, g->B);
-  if (g->C == 4) hipLaunchKernelGGL(conv_s2_first_kernel<4>, grid, dim3(256), (size_t)64 * 100 * sizeof(float), stream, d);
-  else hipLaunchKernelGGL(conv_s2_first_kernel<8>, grid, dim3(256), (size_t)64 * 204 * sizeof(float), stream, d);
+  const bool f16 = ep && ep->mfma_f16;
+  if (g->C == 4 && f16) hipLaunchKernelGGL((conv_s2_first_kernel<4, true>), grid, dim3(256), (size_t)64 * 120 * sizeof(_Float16), stream, d);
+  else if (g->C == 4) hipLaunchKernelGGL((conv_s2_first_kernel<4, false>), grid, dim3(256), (size_t)64 * 100 * sizeof(float), stream, d);
+  else if (f16) hipLaunchKernelGGL((conv_s2_first_kernel<8, true>), grid, dim3(256), (size_t)64 * 216 * sizeof(_Float16), stream, d);
+  else hipLaunchKernelGGL((conv_s2_first_kernel<8, false>), grid, dim3(256), (size_t)64 * 204 * sizeof(float), stream, d);
   return check_launch("conv_s2_first_kernel");
 }
 
@@ -1632,6 +1686,12 @@ extern "C" int32_t ali_conv_tile_order(const AliConvGeom* g, int32_t which, int3
 extern "C" int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which) {
   (void)which;
   return geom_ok(g) ? 1 : 0;       // every mfma_f16 launch of the GEMM kernel does, whatever arithmetic its loop uses
+}
+
+extern "C" int32_t ali_conv_uses_f16(const AliConvGeom* g, int32_t which, const AliEpilogue* ep) {
+  if (!geom_ok(g) || !ep || !ep->mfma_f16) return 0;
+  if (which == 0 && conv_s2_first_ok(g, ep)) return 1;          // row-walking first-layer kernel, fp16 variant
+  return ((which == 0 ? g->C : g->K) % 32) == 0 ? 1 : 0;        // uniform-tap GEMM loop
 }
 
 static int conv_fwd_impl(const AliConvGeom* g, const float* x, const float* w, float* y, const AliEpilogue* ep,

@@ -96,7 +96,7 @@ typedef struct {
   /* fp16 twins (mfma_f16 launches only; all optional): in16 / w16 = the gathered operand and the packed weights as
    * fp16 arrays of the same shapes -- when both are given and the input channel stride % 64 == 0 the kernel reads them
    * instead of x / w (half the bytes, no conversion); out16 = where to leave the fp16 twin of the output for the next
-   * layer.  A launch that cannot run on fp16 MFMA (first layers: 4-8 input channels) ignores in16 / w16 and keeps fp32
+   * layer.  A launch that cannot run on fp16 MFMA (ali_conv_uses_f16 = 0) ignores in16 / w16 and keeps fp32
    * arithmetic, but still leaves out16, so that the layer behind it reads fp16 operands (ali_conv_writes_out16). */
   const void* in16;
   const void* w16;
@@ -173,6 +173,10 @@ int32_t ali_conv_tile_order(const AliConvGeom* g, int32_t which, int32_t mfma_f1
 /* 1 if the launch ali_conv_fwd (which = 0) / ali_conv_bwd_data (which = 1) makes for g with mfma_f16 = 1 writes
  * AliEpilogue.out16 (every valid geometry does). */
 int32_t ali_conv_writes_out16(const AliConvGeom* g, int32_t which);
+/* 1 if that launch, given ep (mfma_f16 = 1), multiplies fp16-rounded operands: the uniform-tap GEMM loop (gathered
+ * channel count % 32 == 0) and the first Conv2d of the spectrogram stacks (4 / 8 -> 64 channels, 5x5, stride 2,
+ * audio_mnist.py:186); every other launch keeps fp32 arithmetic.  What a checker has to know to emulate the launch. */
+int32_t ali_conv_uses_f16(const AliConvGeom* g, int32_t which, const AliEpilogue* ep);
 int ali_conv_fwd(const AliConvGeom* g, const float* x, const float* w_kxc, float* y,
                  const AliEpilogue* ep, void* ws, size_t ws_bytes, ali_stream_t stream);
 int ali_conv_bwd_data(const AliConvGeom* g, const float* dy, const float* w_cxk, float* dx,
@@ -392,6 +396,15 @@ int ali_plane_table_grad(const float* g, int32_t g_ld, int32_t g_ch, const float
 int ali_col2im(const float* contrib, int32_t ldc, const float* bias, float* out, int32_t B, int32_t H, int32_t W,
                int32_t Hout, int32_t Wout, int32_t NC, int32_t ostride, int32_t R, int32_t S, int32_t stride,
                int32_t pad, int32_t act, float slope, ali_stream_t stream);
+/* The two halves above in ONE launch, for 64-channel maps and at most two output channels (what the spectrogram stacks
+ * have at their one-channel ends): x [B,H,W,64] times the tap matrix w_nc [NC*R*S][64] (row (r*S+s)*NC + c, the layout
+ * the 1x1 GEMM takes) on the matrix cores in exact fp32, contributions kept in LDS per output tile, then the sum and
+ * epilogue of ali_col2im -- the [pixels][taps] tensor is never written.  ali_tconv_scatter_ok tells whether a shape is
+ * served (otherwise: ali_conv_fwd + ali_col2im). */
+int32_t ali_tconv_scatter_ok(int32_t C, int32_t NC, int32_t R, int32_t S, int32_t stride);
+int ali_tconv_scatter(const float* x, const float* w_nc, const float* bias, float* out, int32_t B, int32_t H, int32_t W,
+                      int32_t C, int32_t Hout, int32_t Wout, int32_t NC, int32_t ostride, int32_t R, int32_t S,
+                      int32_t stride, int32_t pad, int32_t act, float slope, ali_stream_t stream);
 
 /* Tail of the spectrogram front-end (the step in front of the path): torchaudio.transforms.Spectrogram
  * (power 2) + (. + 1e-6).log() and, optionally, spect_to_img (audio_mnist.py:116,347-363 and copies).  `y` holds, per

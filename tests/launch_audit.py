@@ -59,8 +59,11 @@ class LaunchAudit:
         assert err <= tol * scale, f"launch audit: {what}: max err {err:.3e} vs scale {scale:.3e}"
 
     @staticmethod
-    def _runs_f16(ep, c_gather):
-        return bool(ep.mfma_f16) and c_gather % 32 == 0
+    def _runs_f16(g, which, ep):
+        """does this launch multiply fp16-rounded operands (include/ali_hip.h: ali_conv_uses_f16)"""
+        import ctypes
+        import ali_hip
+        return bool(ali_hip.load().ali_conv_uses_f16(ctypes.byref(g), which, ctypes.byref(ep)))
 
     # ------------------------------------------------------------------
     def gemm(self, kind, g, a, w, out, ep, in_ld, out_ld):
@@ -68,7 +71,7 @@ class LaunchAudit:
         B, H, W, C, P, Q, K, R, S, stride, pad = _geom(g)
         refs = getattr(ep, "refs", {})
         if kind == "fwd":          # a = x [B,H,W,C], w = [K][R*S][C], out = y [B,P,Q,K]
-            f16 = self._runs_f16(ep, C)
+            f16 = self._runs_f16(g, 0, ep)
             x = a.detach().reshape(B, H, W, C).cpu()
             wt = w.detach().cpu().reshape(K, R, S, C).permute(0, 3, 1, 2)
             if f16:
@@ -76,7 +79,7 @@ class LaunchAudit:
             ref = F.conv2d(x.permute(0, 3, 1, 2), wt, stride=stride, padding=pad).permute(0, 2, 3, 1)
             n_out, oshape = K, (B, P, Q, K)
         else:                      # a = dy [B,P,Q,K], w = [C][R*S][K], out = dx [B,H,W,C]
-            f16 = self._runs_f16(ep, K)
+            f16 = self._runs_f16(g, 1, ep)
             dy = a.detach().reshape(B, P, Q, K).cpu()
             wt = w.detach().cpu().reshape(C, R, S, K).permute(3, 0, 1, 2)          # [K][C][R][S]
             if f16:
@@ -97,6 +100,23 @@ class LaunchAudit:
         self._cmp(got, ref, f"{kind} {(B, H, W, C, P, Q, K, R, stride, pad)}{' f16' if f16 else ''}")
         self.checked[kind] += 1
         self.f16_checked += int(f16)
+
+    # ------------------------------------------------------------------
+    def scatter(self, x, w_nc, bias, out, dims, act, slope):
+        """ali_tconv_scatter: ConvTranspose2d(C -> NC) of x with the tap matrix w_nc [(r*S+s)*NC + c][C], exact fp32"""
+        torch.cuda.synchronize()
+        B, H, W, C, Hout, Wout, NC, ostride, R, S, stride, pad = dims
+        xs = x.detach().reshape(B, H, W, C).cpu().permute(0, 3, 1, 2)
+        wt = w_nc.detach().cpu().reshape(R, S, NC, C).permute(3, 2, 0, 1)                    # [C][NC][R][S]
+        opad = (Hout - ((H - 1) * stride - 2 * pad + R), Wout - ((W - 1) * stride - 2 * pad + S))
+        ref = F.conv_transpose2d(xs, wt, stride=stride, padding=pad, output_padding=opad).permute(0, 2, 3, 1)
+        if bias is not None:
+            ref = ref + bias.detach().cpu().reshape(1, 1, 1, -1)[..., :NC]
+        ref = _act(ref, int(act), float(slope))
+        got = torch.as_strided(out.detach(), (B, Hout, Wout, NC), (Hout * Wout * ostride, Wout * ostride, ostride, 1),
+                               out.storage_offset()).cpu()
+        self._cmp(got, ref, f"scatter {dims}")
+        self.checked["fwd"] += 1
 
     # ------------------------------------------------------------------
     def wgrad(self, g, x, dy, dst, cg_log, cd_log, strides, db, dy_ld):

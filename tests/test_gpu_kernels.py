@@ -284,6 +284,48 @@ def test_col2im_gathers_scatter_form_transposed_conv(Co, stride, pad, opad, R):
     close(nchw(out), ref, rtol=1e-5, what="col2im")
 
 
+@pytest.mark.parametrize("B,H,W,Co,stride,pad,opad,R,act", [
+    (3, 20, 28, 1, 2, 2, 1, 5, "tanh"),     # Generator tail of the spectrogram stacks (audio_mnist.py:243), small
+    (2, 70, 90, 1, 2, 2, 1, 5, "none"),     # several output tiles per image, ragged edges
+    (2, 31, 31, 1, 2, 1, 1, 5, "none"),     # first Conv2d's consumed input plane: 31^2 x 64 -> 64^2 (pad 1)
+    (2, 40, 33, 2, 2, 1, 0, 4, "leaky"),    # two output channels, 4x4
+    (2, 25, 25, 1, 1, 0, 0, 3, "none"),     # stride 1
+    (1, 9, 150, 2, 3, 1, 2, 5, "tanh"),     # stride 3, wide
+])
+def test_fused_scatter_transposed_conv(B, H, W, Co, stride, pad, opad, R, act):
+    """ali_tconv_scatter (tap contributions on the matrix cores, kept in LDS, summed per output pixel: one launch)
+    == F.conv_transpose2d with bias and activation, and == the two-launch form (1x1 GEMM + ali_col2im) it replaces."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 7 + H + R)
+    Ci = 64
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Ci, Co, R, R, generator=g) / (Ci * R * R / stride ** 2) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    a_id, fn = {"tanh": (ops.ACT_TANH, torch.tanh), "none": (ops.ACT_NONE, lambda v: v),
+                "leaky": (ops.ACT_LEAKY, lambda v: F.leaky_relu(v, 0.2))}[act]
+    ref = fn(F.conv_transpose2d(x, w, b, stride=stride, padding=pad, output_padding=opad))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    assert ops.tconv_scatter_ok(Ci, Co, R, R, stride)
+    wn = w.reshape(Ci, Co, R * R).permute(2, 1, 0).reshape(R * R * Co, Ci).contiguous().cuda()    # rows tap * Co + co
+    xh = nhwc(x).cuda()
+    out = torch.full((B, Ho, Wo, Co), float("nan"), device="cuda")
+    ops.tconv_scatter(xh, wn, b.cuda(), out, B, H, W, Ci, Ho, Wo, Co, Co, R, R, stride, pad, a_id, 0.2)
+    close(nchw(out), ref, what="fused scatter transposed conv")
+    contrib = torch.empty(B, H, W, Co * R * R, device="cuda")
+    ops.conv_fwd(ops.geom(B, H, W, Ci, H, W, Co * R * R, 1, 1, 1, 0), xh, wn.reshape(Co * R * R, 1, Ci), contrib, ops.epilogue())
+    two = torch.empty(B, Ho, Wo, Co, device="cuda")
+    ops.col2im(contrib, Co * R * R, b.cuda(), two, B, H, W, Ho, Wo, Co, Co, R, R, stride, pad, a_id, 0.2)
+    close(out, two, rtol=2e-5, what="fused vs GEMM + col2im")
+    # strided output (one plane of a wider tensor)
+    wide = torch.zeros(B, Ho, Wo, Co + 3, device="cuda")
+    ops.tconv_scatter(xh, wn, None, wide, B, H, W, Ci, Ho, Wo, Co, Co + 3, R, R, stride, pad)
+    assert wide[..., Co:].abs().max().item() == 0.0
+    close(nchw(wide[..., :Co].contiguous()), F.conv_transpose2d(x, w, None, stride=stride, padding=pad, output_padding=opad),
+          what="fused scatter, strided output")
+    with ops.tuning(ALI_NO_T1_MFMA=1):
+        assert not ops.tconv_scatter_ok(Ci, Co, R, R, stride)
+
+
 @pytest.mark.parametrize("n_fft,win,hop,pad,L", [(255, 128, None, 96, 8000), (511, 128, 24, 64, 2900),
                                                    (1023, 256, 79, 200, 9000)])
 def test_spectrogram_front_end_vs_torch_stft(n_fft, win, hop, pad, L):
@@ -745,8 +787,8 @@ def test_spectrogram_layers_at_the_bench_batch(name, precision):
     ops = _ops()
     kind, B, C, Cl, H, K, R, stride, pad, opad = SPECT_FULL[name]
     f16 = precision != "f32"
-    if f16 and C % 32:
-        pytest.skip("first layers (channel stride % 32 != 0) keep fp32 arithmetic")
+    if f16 and C % 32 and precision != "f16":
+        pytest.skip("first layers (4 / 8 channels) read no fp16 twins")     # (f16: the row-walking kernel's fp16 variant)
     tol = 4e-3 if f16 else 2e-4
     g = torch.Generator(device="cuda").manual_seed(23)
     T = R * R
@@ -936,7 +978,11 @@ F16_CASES = [
 ]
 
 
-@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", F16_CASES)
+# first Conv2d of the spectrogram stacks (audio_mnist.py:186): conv_s2_first_kernel's fp16 variant, 4 / 8 channels
+F16_FIRST_CASES = [("conv", 2, 4, 70, 64, 5, 2, 1), ("conv", 2, 8, 67, 64, 5, 2, 1), ("conv", 1, 4, 96, 64, 5, 2, 2)]
+
+
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", F16_CASES + F16_FIRST_CASES)
 def test_fp16_mfma_gemm_path(kind, B, C, H, K, R, stride, pad, forced_tile):
     """AliEpilogue.mfma_f16 (BASELINE config 5): operands rounded to fp16 on their way into LDS, fp32 accumulation.
     (i) On data that fp16 holds exactly (small integers / powers of two) the result must EQUAL the fp32 path's bit for
