@@ -32,6 +32,7 @@ struct Tuning {
   int wbm, wbn;                             // ALI_WBM / ALI_WBN: force the weight-gradient tile (one of its variants)
   int no_xcd;                               // ALI_NO_XCD=1: raster tile order on deep grids instead of XCD-contiguous chunks (A/B)
   int no_s2_first;                          // ALI_NO_S2_FIRST=1: the spectrogram stacks' first conv stays an implicit GEMM (A/B)
+  int no_dma16;                             // ALI_NO_DMA16=1: fp16 twins are always staged through registers (A/B of the LDS-DMA loop)
   int no_t1_mfma;                           // ALI_NO_T1_MFMA=1: the VALU gather forms of the direct one-channel kernels (A/B)
 };
 inline Tuning read_tuning() {
@@ -48,6 +49,7 @@ inline Tuning read_tuning() {
     v.no_t1_mfma = (int)num("ALI_NO_T1_MFMA");
     v.no_xcd = (int)num("ALI_NO_XCD");
     v.no_s2_first = (int)num("ALI_NO_S2_FIRST");
+    v.no_dma16 = (int)num("ALI_NO_DMA16");
     return v;
   }
 }

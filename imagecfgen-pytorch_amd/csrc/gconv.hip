@@ -116,17 +116,20 @@ constexpr int LDH = 40;      // fp16 LDS rows: 32 halves + 8 pad = 80 B (16-B al
 // The kernel's body.  (bx_, by_, bz_) = the block's 3-D index in a plain launch; u_ = its linear index in a 1-D
 // ("lin1d": tail-split / cost-ordered) launch.  A job of a multi-job launch (gconv_multi_kernel) passes the same values,
 // decoded from its share of that launch's 1-D grid.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int F16 = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int F16 = 0, int NT = 256>
 __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const int by_, const int bz_, const int u_) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int AP = BM / 32, BP = BN / 32;  // 16-byte gathers per thread per k-tile
+  constexpr int RPP = NT / 8;                // operand rows a pass of the block's threads stages (8 threads per row)
+  constexpr int AP = BM / RPP, BP = BN / RPP;  // 16-byte gathers per thread per k-tile
+  constexpr bool DMA = F16 == 3;             // fp16 twins straight into LDS (buffer_load ... lds), see the k-loop
+  constexpr int LDX = DMA ? 32 : LDK;        // LDS row pitch in floats (DMA: 128-byte rows, no pad: swizzled)
   constexpr int NL = AP + BP;
   constexpr int NMF = 16 * TM * TN;          // MFMAs per wave per k-tile
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(WAVES_M * WAVES_N * 64 == NT, "one wave per 64 threads");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+  __shared__ __attribute__((aligned(1024))) float As[2][BM * LDX];
+  __shared__ __attribute__((aligned(1024))) float Bs[2][BN * LDX];
   __shared__ int s_rowoff[BM];  // element offset of the row's output pixel (host guarantees < 2^31), -1 = none
   __shared__ int s_rowimg[BM];
   __shared__ int s_tap[kMaxTaps];                                  // dh | dw<<8 | wt<<16 (generic path)
@@ -220,7 +223,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
       fast_divmod(t2, P.Hq, rH, img, qh);
     }
   };
-  for (int r = t; r < BM; r += 256) {
+  for (int r = t; r < BM; r += NT) {
     const int m = m0 + r;
     int off = -1, img = 0;
     if (m < P.M) {
@@ -240,7 +243,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
   unsigned blockmask = 0u;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + r0 + RPP * i;
     const bool valid = m < P.M;
     int qw, qh, img;
     decode(valid ? m : 0, img, qh, qw);
@@ -281,9 +284,9 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
   f32x4 ra1[AP], rb1[BP];   // fast path: the odd tiles -- two k-tiles of gathers are in flight
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = ra[i];
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&As[buf][(r0 + RPP * i) * LDK + c4 * 4]) = ra[i];
 #pragma unroll
-    for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * j) * LDK + c4 * 4]) = rb[j];
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + RPP * j) * LDK + c4 * 4]) = rb[j];
   };
   const int lrow = lane & 31, lh = lane >> 5;
   const float* Ab = &As[0][(wm * WM + lrow) * LDK + lh * 4];
@@ -331,7 +334,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
     for (int i = 0; i < AP; ++i) aoffB[i] = (unsigned)(aoff[i] + ccol) * 4u;
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-      const int n = n0 + r0 + 32 * j;
+      const int n = n0 + r0 + RPP * j;
       woffB[j] = n < d.Cout ? (unsigned)(((long long)n * d.ldw + ccol) * 4) : OOB;
     }
     struct Ctx { int doff, woff; unsigned bit; };
@@ -359,7 +362,86 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
     };
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
-    if (F16 == 2) {
+    if constexpr (F16 == 3) {
+      // ---- fp16 operands in memory, staged by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write.
+      // The register-staged loop above spends 13 LDS cycles per ds_write_b128 and is bound by L2 -> CU bytes at 128 x 128
+      // (DESIGN.md 3.4 / 3.6); here a 512-thread block owns 256 x 256 outputs (8 waves of 128 x 64: half the operand
+      // bytes per FLOP) and the accumulators may take half the register file because nothing is staged through it.
+      // A wave-instruction writes 1 KiB of LDS linearly (base + 16 * lane) = 8 rows x 128 B: lane (row r, slot s) fetches
+      // the row's chunk s ^ ((r >> 1) & 7), the fragment reads apply the same XOR -- conflict-free ds_read_b128 without
+      // padding.  Two stages: tile q+1 is in flight while tile q is multiplied; per k-tile one counted wait (vmcnt(0):
+      // this wave's pieces of tile q have landed), one raw barrier (every wave's have, and every wave is done reading
+      // the other stage), then the next tile's DMA goes into that other stage.  Same k order as the F16 == 2 loop:
+      // bit-identical results.  (Host: only without split-K; out-of-range rows / padding taps fetch zeros.)
+      constexpr int BK16 = 64;
+      const int cpt16 = Cin / BK16;
+      const int total16 = nlive * cpt16;
+      const int per16 = (total16 + nsplit - 1) / nsplit;
+      const int qb16 = bz * per16;
+      const int qe16 = min(total16, qb16 + per16);
+      const __amdgpu_buffer_rsrc_t rin16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.in16, 0, d.in_bytes / 2, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rw16 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w16, 0, d.w_bytes / 2, 0x00020000);
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      const int csw = c4 ^ ((r0 >> 1) & 7);                      // (RPP is a multiple of 16: the same for every pass)
+      unsigned aoffS[AP], woffS[BP];
+#pragma unroll
+      for (int i = 0; i < AP; ++i) aoffS[i] = (unsigned)(aoff[i] + csw * 8) * 2u;
+#pragma unroll
+      for (int j = 0; j < BP; ++j) {
+        const int n = n0 + r0 + RPP * j;
+        woffS[j] = n < d.Cout ? (unsigned)(((long long)n * d.ldw + csw * 8) * 2) : OOB;
+      }
+      auto issue = [&](int li, int ch, int stage) {
+        const int4 ti = *reinterpret_cast<const int4*>(&s_live[li][0]);
+        const unsigned doff = (unsigned)((ti.x >> 1) + ch * (BK16 * 2)), woff = (unsigned)((ti.y >> 1) + ch * (BK16 * 2));
+        const unsigned bit = (unsigned)ti.z;
+        float* ab = &As[stage][wave * 8 * 32];
+        float* bb = &Bs[stage][wave * 8 * 32];
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          const unsigned off = (amask[i] & bit) ? aoffS[i] + doff : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rin16, (lds_ptr)(ab + i * RPP * 32), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+          const unsigned off = woffS[j] >= OOB ? OOB : woffS[j] + woff;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw16, (lds_ptr)(bb + j * RPP * 32), 16, (int)off, 0, 0, 0);
+        }
+      };
+      if (qb16 < qe16) {
+        int q = qb16;
+        int li = q / cpt16, ch = q - li * cpt16;
+        issue(li, ch, 0);
+        int stage = 0;
+        const int swz = (lrow >> 1) & 7;
+        for (; q < qe16; ++q) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (++ch == cpt16) { ch = 0; ++li; }
+          if (q + 1 < qe16) issue(li, ch, stage ^ 1);
+          const float* Ac = &As[stage][(wm * WM + lrow) * 32];
+          const float* Bc = &Bs[stage][(wn * WN + lrow) * 32];
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            const int pc = ((2 * st + lh) ^ swz) * 4;
+            f16x8 ha[TM], hb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+              ha[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 32 + pc));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              hb[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(Bc + j * 32 * 32 + pc));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+          }
+          stage ^= 1;
+        }
+      }
+      __syncthreads();       // (the epilogues reuse the operand tiles as scratch)
+    } else if (F16 == 2) {
       // ---- fp16 operands in memory: k-tile = 64 halves.  Offsets below are the fp32 path's halved (bytes of halves).
       constexpr int BK16 = 64;
       const int cpt16 = Cin / BK16;
@@ -374,7 +456,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
       for (int i = 0; i < AP; ++i) aoffH[i] = (unsigned)(aoff[i] + c4 * 8) * 2u;
 #pragma unroll
       for (int j = 0; j < BP; ++j) {
-        const int n = n0 + r0 + 32 * j;
+        const int n = n0 + r0 + RPP * j;
         woffH[j] = n < d.Cout ? (unsigned)(((long long)n * d.ldw + c4 * 8) * 2) : OOB;
       }
       auto ctx16 = [&](int li, int ch, bool live) -> Ctx {
@@ -403,10 +485,10 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
       auto store16 = [&](int buf, auto SET) {   // 16 bytes = 8 halves per lane: the fp32 tile's LDS image as it stands
 #pragma unroll
         for (int i = 0; i < AP; ++i)
-          *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = decltype(SET)::value ? ra1[i] : ra[i];
+          *reinterpret_cast<f32x4*>(&As[buf][(r0 + RPP * i) * LDK + c4 * 4]) = decltype(SET)::value ? ra1[i] : ra[i];
 #pragma unroll
         for (int j = 0; j < BP; ++j)
-          *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * j) * LDK + c4 * 4]) = decltype(SET)::value ? rb1[j] : rb[j];
+          *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + RPP * j) * LDK + c4 * 4]) = decltype(SET)::value ? rb1[j] : rb[j];
       };
       if (qb16 < qe16) {
         int q = qb16;
@@ -462,13 +544,13 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
           for (int i = 0; i < AP; ++i) {
             const f32x4 s = set ? ra1[i] : ra[i];
             const f16x4 v = {(_Float16)s[0], (_Float16)s[1], (_Float16)s[2], (_Float16)s[3]};
-            *reinterpret_cast<f16x4*>(&Ah[(buf * BM + r0 + 32 * i) * LDH + c4 * 4]) = v;
+            *reinterpret_cast<f16x4*>(&Ah[(buf * BM + r0 + RPP * i) * LDH + c4 * 4]) = v;
           }
 #pragma unroll
           for (int j = 0; j < BP; ++j) {
             const f32x4 s = set ? rb1[j] : rb[j];
             const f16x4 v = {(_Float16)s[0], (_Float16)s[1], (_Float16)s[2], (_Float16)s[3]};
-            *reinterpret_cast<f16x4*>(&Bh[(buf * BN + r0 + 32 * j) * LDH + c4 * 4]) = v;
+            *reinterpret_cast<f16x4*>(&Bh[(buf * BN + r0 + RPP * j) * LDH + c4 * 4]) = v;
           }
         };
         int q = qb;
@@ -600,8 +682,8 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
 #pragma unroll
               for (int x = 0; x < NL; ++x) {
                 if ((x * Q) / NL != sw) continue;
-                if (x < AP) *reinterpret_cast<f32x4*>(Aw + 32 * x * LDK) = fetch ? ra[x] : ra1[x];
-                else *reinterpret_cast<f32x4*>(Bw + 32 * (x - AP) * LDK) = fetch ? rb[x - AP] : rb1[x - AP];
+                if (x < AP) *reinterpret_cast<f32x4*>(Aw + RPP * x * LDK) = fetch ? ra[x] : ra1[x];
+                else *reinterpret_cast<f32x4*>(Bw + RPP * (x - AP) * LDK) = fetch ? rb[x - AP] : rb1[x - AP];
               }
             }
           }
@@ -628,7 +710,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
     bool bvalid[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
-      const int n = n0 + r0 + 32 * j;
+      const int n = n0 + r0 + RPP * j;
       bvalid[j] = n < d.Cout;
       wptr[j] = d.w + (long long)(bvalid[j] ? n : 0) * d.ldw;
     }
@@ -846,7 +928,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
   using BN2 = std::integral_constant<int, 2>;
   using T_ = std::true_type;
   using F_ = std::false_type;
-  if (nsplit > 1) {
+  if (!DMA && nsplit > 1) {          // (the LDS-DMA kernel is launched without split-K: no slab code in its register budget)
     // split-K: every block stores its raw partial tile in its slab; the block that arrives last at the tile's
     // counter sums the slabs in slab order (deterministic whichever block that is) and runs the real epilogue.
     // Slab stores / loads are device-scope (sc1) accesses -- written through to memory, never served from another
@@ -944,6 +1026,12 @@ __global__ __launch_bounds__(256, 2) void gconv_kernel(const GDesc d) {
   gconv_body<BM, BN, WAVES_M, WAVES_N, MODE, F16>(d, blockIdx.x, blockIdx.y, blockIdx.z, blockIdx.x);
 }
 
+// 512-thread variant (the LDS-DMA fp16 loop: 8 waves, one block per CU)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, int F16>
+__global__ __launch_bounds__(512, 1) void gconv_kernel512(const GDesc d) {
+  gconv_body<BM, BN, WAVES_M, WAVES_N, MODE, F16, 512>(d, blockIdx.x, blockIdx.y, blockIdx.z, blockIdx.x);
+}
+
 // Several independent GEMM launches of the same kernel variant in ONE launch (ali_gemm_launch_multi): the Encoder and the
 // Generator of an ALI iteration (mnist.py:224-226), the two branches of its backward pass, the dz / dx stacks of the
 // Discriminator are independent chains, so their layers go out pairwise -- half the launch boundaries, and the small
@@ -1000,7 +1088,10 @@ static TileCfg pick_tile(long long M, int N, bool f16, int cin) {
 }
 
 // tile shape, row order and M-tile count of a launch (everything the grid's x extent depends on)
-static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps) {
+// dma_ok: the launch may use the 256 x 256 LDS-DMA fp16 kernel (both fp16 twins present, see finalize_and_launch); the
+// host-side queries (ali_conv_mtiles / ali_conv_tile_order) never say so -- such launches carry no fused BatchNorm, and a
+// dispatch-order table of another tile count is ignored by the launch
+static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps, bool dma_ok = false) {
   long long Mtot = 0;
   max_taps = 0;
   for (int i = 0; i < d.nphase; ++i) {
@@ -1009,8 +1100,21 @@ static int plan_tiles(GDesc& d, bool vec, TileCfg& tc, int& max_taps) {
     if (d.ph[i].M >= (1 << 24)) { set_error("gconv: more than 2^24 rows in one phase"); return -1; }
   }
   const bool f16_loop = d.f16 && vec && (d.Cin % BK) == 0;
-  tc = pick_tile(Mtot * (tuning().tile_m_scale > 0 ? tuning().tile_m_scale : 1), d.Cout, f16_loop, d.Cin);
+  const long long Mpick = Mtot * (tuning().tile_m_scale > 0 ? tuning().tile_m_scale : 1);
+  tc = pick_tile(Mpick, d.Cout, f16_loop, d.Cin);
   if (tuning().bm > 0 && tuning().bn > 0) { tc.bm = tuning().bm; tc.bn = tuning().bn; }
+  if (tc.bm > 128 && !dma_ok) tc = pick_tile(Mpick, d.Cout, f16_loop, d.Cin);      // (a forced 256 x 256 applies to DMA launches only)
+  if (dma_ok && tuning().bm == 0) {
+    // 256 x 256 as soon as it fills the chip once (one block per CU).  Stand-alone (scratch/ub/dma_gemm.hip, a 1-D
+    // "convolution" with the layers' reuse): 881-1008 TF/s against 700-840 of the 128 x 128 register-staged loop.  Inside
+    // the ESRF iteration the forward convolutions 128 -> 256 ... 512 -> 1024 gain 5-8 % (697 -> 732, 781 -> 842, 783 ->
+    // 849 TF/s); launches in sub-pixel phases (data gradients: 786 -> 591) and tiny pixel-major maps (7 x 7: 911 -> 810)
+    // LOSE -- a 256-row tile spans two pixel positions, so fewer padding taps are skipped tile-wide, and there is no
+    // cost-ordered dispatch table for this tile: they keep the 128 x 128 loop.
+    const long long b256 = ((Mpick + 255) / 256) * (long long)((d.Cout + 255) / 256);
+    const bool plain = d.nphase == 1 && (long long)d.ph[0].Hq * d.ph[0].Wq >= 200;
+    if (plain && d.Cout >= 256 && b256 >= (kNumCU * 3) / 4) { tc.bm = 256; tc.bn = 256; }
+  }
   if (!vec && tc.bn == 128) tc.bn = 64;
   int tiles = 0;
   for (int i = 0; i < d.nphase; ++i) {
@@ -1063,10 +1167,14 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
                                AliGemmJob* job = nullptr) {
   TileCfg tc;
   int max_taps = 0;
-  const int tiles = plan_tiles(d, vec, tc, max_taps);
-  if (tiles < 0) return ALI_ERR_BAD_ARG;
-  const int max_nkt = (max_taps * d.Cin + BK - 1) / BK;
   const bool uni = vec && (d.Cin % BK) == 0;
+  // (fp16 launches are never recorded as jobs of a combined launch: a job pointer does not matter here)
+  const bool dma_ok = d.f16 && uni && d.in16 && d.w16 && (d.Cin % 64) == 0 && !d.ep.bn_part && d.ep.in_ld <= 0 &&
+                      tuning().no_dma16 == 0 && tuning().splitk == 0;
+  const int tiles = plan_tiles(d, vec, tc, max_taps, dma_ok);
+  if (tiles < 0) return ALI_ERR_BAD_ARG;
+  const bool dma = tc.bm == 256;
+  const int max_nkt = (max_taps * d.Cin + BK - 1) / BK;
   const bool pow2 = vec && (d.Cin == 4 || d.Cin == 8 || d.Cin == 16) && max_taps <= kMaxTaps;
   if (d.ep.bn_part) {
     const AliEpilogue& e = d.ep;
@@ -1128,6 +1236,7 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   }
   if (tuning().splitk > 0 && (size_t)tuning().splitk * d.out_elems * sizeof(float) <= ws_payload_bytes(ws_bytes))
     S = tuning().splitk;
+  if (dma) S = 1;                      // (the LDS-DMA kernel runs whole k-loops only)
   if (blocks > (long long)(kWsReserved / sizeof(int)) || !ws) S = 1;   // one arrival counter per tile
   while (S > 1 && (long long)S * d.out_elems * 4 >= 0xFF000000LL) --S;  // slabs addressed with 32-bit byte offsets
   d.splitk = S;
@@ -1142,7 +1251,7 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
   d.tail_split = 1;
   d.tail_u0 = 0;
   if (S == 1 && uni && ws && blocks > kNumCU && blocks < 4 * kNumCU && blocks <= (long long)(kWsReserved / sizeof(int))
-      && tuning().splitk == 0) {
+      && tuning().splitk == 0 && !dma) {
     const int R = (int)(blocks % kNumCU);
     int Sr = 1;
     while (R > 0 && Sr * 2 <= 8 && Sr * 2 * R <= kNumCU && max_nkt / (Sr * 2) >= 4) Sr *= 2;
@@ -1197,6 +1306,12 @@ static int finalize_and_launch(GDesc& d, void* ws, size_t ws_bytes, hipStream_t 
     else if (vec) hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 1>), grid, block, 0, stream, d); \
     else hipLaunchKernelGGL((gconv_kernel<BM_, BN_, WMM, WNN, 0>), grid, block, 0, stream, d);          \
   } while (0)
+  if (dma) {
+    if (tc.bn != 256 || !op16) { set_error("gconv: no kernel for this tile"); return ALI_ERR_BAD_ARG; }
+    block = dim3(512);
+    hipLaunchKernelGGL((gconv_kernel512<256, 256, 2, 4, 2, 3>), grid, block, 0, stream, d);
+    return check_launch("gconv_kernel512");
+  }
   if (tc.bm > 128 || tc.bn > 128) { set_error("gconv: no kernel for this tile"); return ALI_ERR_BAD_ARG; }
   else if (tc.bm == 128 && tc.bn == 128) LAUNCH(128, 128, 2, 2);
   else if (tc.bm == 128 && tc.bn == 64) LAUNCH(128, 64, 2, 2);

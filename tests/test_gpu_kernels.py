@@ -1101,6 +1101,74 @@ def test_fp16_operands_in_memory_path(kind, B, C, H, K, R, stride, pad, forced_t
     assert y_z.abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad,epi", [
+    ("conv", 5, 64, 33, 256, 5, 2, 1, "plain"),       # ragged M (5 * 16^2 rows) and one N-tile
+    ("conv", 3, 128, 31, 320, 5, 2, 1, "bias_act"),   # ragged N (320 = 256 + 64), image-major rows
+    ("conv", 64, 128, 9, 512, 5, 2, 1, "mask"),       # pixel-major rows (B >= 64, small map): padding taps skipped tile-wide
+    ("convT", 3, 256, 9, 128, 5, 2, 2, "plain"),      # data-gradient form: four sub-pixel phases, C_out of the GEMM = 256
+    ("convT", 2, 320, 12, 64, 5, 2, 1, "dact"),       # act' of the previous layer in the epilogue, odd output size
+    ("conv", 2, 192, 1, 256, 1, 1, 0, "plain"),       # 1x1 on a 1x1 map: M = 2
+])
+def test_fp16_lds_dma_kernel(kind, B, C, H, K, R, stride, pad, epi):
+    """gconv_kernel512<256,256,...,F16=3> (fp16 twins by LDS-DMA into a swizzled image, 8 waves): what pick_tile gives the
+    large fp16 layers of the spectrogram benches, forced here on small shapes.  Same products and the same k order as the
+    register-staged twin loop: EQUAL to it bit for bit (ALI_NO_DMA16=1 runs that one), and within fp32 summation rounding
+    of torch's convolution of the fp16-rounded operands."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 3 + C + K)
+    x = torch.randn(B, H, H, C, generator=g).cuda()
+    if kind == "conv":
+        w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+        P = (H + 2 * pad - R) // stride + 1
+        geom, oshape, nout = ops.geom(B, H, H, C, P, P, K, R, R, stride, pad), (B, P, P, K), K
+        wp = pack_conv_fwd(ops, w, C)
+        run = ops.conv_fwd
+        ref = F.conv2d(nchw(x.cpu().half().float()), w.half().float(), stride=stride, padding=pad)
+    else:
+        w = torch.randn(C, K, R, R, generator=g) / (C * R * R / stride ** 2) ** 0.5
+        Ho = (H - 1) * stride - 2 * pad + R + 1
+        geom, oshape, nout = ops.geom(B, Ho, Ho, K, H, H, C, R, R, stride, pad), (B, Ho, Ho, K), K
+        wp = torch.empty(K, R * R, C, device="cuda")
+        ops.pack_weights(w.cuda().contiguous(), wp, K, R * R, C, C, R * R, 1, K * R * R)
+        run = ops.conv_bwd_data
+        ref = F.conv_transpose2d(nchw(x.cpu().half().float()), w.half().float(), stride=stride, padding=pad, output_padding=1)
+    ref = nhwc(ref)
+    bias = torch.randn(nout, generator=g).cuda() * 0.1
+    mask = (torch.rand(B, nout, generator=g) > 0.3).float().cuda() * 1.25
+    yprev = torch.randn(oshape, generator=g).cuda()
+
+    def epilogue():
+        if epi == "bias_act":
+            return ops.epilogue(bias=bias, act=ops.ACT_LEAKY, slope=0.2)
+        if epi == "mask":
+            return ops.epilogue(bias=bias, act=ops.ACT_LEAKY, slope=0.2, mask=mask)
+        if epi == "dact":
+            return ops.epilogue(dact_y=yprev, dact=ops.ACT_LEAKY, dslope=0.2)
+        return ops.epilogue()
+    if epi in ("bias_act", "mask"):
+        ref = F.leaky_relu(ref + bias.cpu(), 0.2)
+    if epi == "mask":
+        ref = ref * mask.cpu().reshape(B, 1, 1, nout)
+    if epi == "dact":
+        ref = ref * torch.where(yprev.cpu() > 0, 1.0, 0.2)
+    x._ali16 = x.half()
+    ops.ensure_shadow16(wp)
+    outs = []
+    for env in ({"ALI_BM": 256, "ALI_BN": 256}, {"ALI_NO_DMA16": 1, "ALI_SPLITK": 1}):   # (whole k-loops in both)
+        with ops.precision("f16"), ops.tuning(**env):
+            y = torch.full(oshape, float("nan"), device="cuda")
+            run(geom, x, wp, y, epilogue())
+            outs.append(y)
+            assert torch.equal(ops.shadow16(y), y.half())          # the fp16 twin for the next layer
+    close(outs[0], ref, what=f"LDS-DMA fp16 kernel ({kind}, {epi})")
+    assert torch.equal(outs[0], outs[1]), "LDS-DMA loop differs from the register-staged twin loop"
+    x._ali16.zero_()                                                  # ... and it really read the twins
+    with ops.precision("f16"), ops.tuning(ALI_BM=256, ALI_BN=256):
+        z = torch.empty(oshape, device="cuda")
+        run(geom, x, wp, z, ops.epilogue())
+    assert z.abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("kind,B,C,H,K,R,stride,pad", [c for c in F16_CASES if c[2] % 8 == 0 and c[4] >= 64])
 def test_fp16_weight_gradient_from_twins(kind, B, C, H, K, R, stride, pad, forced_tile):
     """ali_conv_bwd_weight fed the fp16 twins of both operands (x16 / dy16): same products as the converting fp16 path
