@@ -912,7 +912,7 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
     // nearest: src = floor(dst * 16 / size)  (torch 'nearest', probe-verified in SURVEY.md K8)
     const int sh = (h * 16) / H, sw = (w * 16) / W;
     float* o = out + i * Cpad;
-    if (Cpad == 8) {                     // the MNIST stacks' 5 planes in 8 channels: two 16-byte stores per pixel
+    if (Cpad == 8 || Cpad == 4) {        // 5 planes in 8 channels (MNIST), 2-4 in 4 (whale / ESRF): 16-byte stores per pixel
       float v[8];
       v[0] = X[i];
       int c = 1;
@@ -921,10 +921,11 @@ __global__ void assemble_planes_kernel(const float* __restrict__ X, const int* _
       for (; c < 8; ++c) v[c] = 0.f;
       if (mask) {                        // the Dropout2d in front of the consuming conv, per (sample, channel)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= mask[(long long)b * mask_ld + e];
+        for (int e = 0; e < 8; ++e)
+          if (e < Cpad) v[e] *= mask[(long long)b * mask_ld + e];
       }
       *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      if (Cpad == 8) *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
       continue;
     }
     o[0] = X[i];
