@@ -112,6 +112,9 @@ SIGNATURES = {
                                        c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "ali_col2im": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 12 + [c_float, c_void_p]),
     "ali_tconv_scatter_ok": (c_int32, [c_int32] * 5),
+    "ali_tconv_scatter_wgrad_ws": (c_int64, [c_int32] * 7),
+    "ali_tconv_scatter_wgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64] + [c_int32] * 10
+                                + [c_void_p, c_size_t, c_void_p]),
     "ali_tconv_scatter": (c_int32, [c_void_p] * 4 + [c_int32] * 13 + [c_float, c_void_p]),
     "ali_tconv1_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_float, c_void_p, c_int32,
                                                                                             c_void_p]),

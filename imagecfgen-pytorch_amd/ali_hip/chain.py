@@ -672,8 +672,16 @@ def chain_backward_gen(plan: ChainPlan, saved, gy: torch.Tensor, c_log_in: int, 
                                  m.padding[0])
             elif st.kind == "convT":
                 T = m.kernel_size[0] * m.kernel_size[1]
-                # gathered operand = convT output-grad (channels K), dense = convT input (channels Cp)
-                ops.conv_bwd_weight(g, g_pre, sv.t, dw, K, c_in_log, dw.stride(0), dw.stride(1), dw.stride(3), defer=fold)
+                done = None
+                if (m.out_channels == 1 and Cp == 64 and c_in_log == 64 and not ld and sv.t.is_contiguous()
+                        and g_pre.is_contiguous() and dw.stride(2) == m.kernel_size[1] * dw.stride(3)):
+                    # one-channel tail (stride 2): pixel-contraction kernel instead of a GEMM with one gathered channel
+                    done = ops.tconv_scatter_wgrad(sv.t, g_pre, 1, dw, dw.stride(0), dw.stride(3), B, H, W, Cp, P, Q,
+                                                   m.kernel_size[0], m.kernel_size[1], m.stride[0], m.padding[0])
+                if done is None:
+                    # gathered operand = convT output-grad (channels K), dense = convT input (channels Cp)
+                    ops.conv_bwd_weight(g, g_pre, sv.t, dw, K, c_in_log, dw.stride(0), dw.stride(1), dw.stride(3),
+                                        defer=fold)
             else:
                 O, I = m.weight.shape
                 Cc, hh, ww = st.unflat if st.unflat else (O, 1, 1)

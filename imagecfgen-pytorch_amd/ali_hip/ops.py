@@ -949,6 +949,23 @@ def tconv_scatter(x, w_nc, bias, out, B, H, W, C, Hout, Wout, NC, ostride, R, S,
     return out
 
 
+def tconv_scatter_wgrad(big, small, sstride, dw, s_k, s_tap, B, P, Q, K, H, W, R, S, stride, pad):
+    """Weight gradient of a strided ConvTranspose2d(64 -> 1) in one launch + slab fold (include/ali_hip.h:
+    ali_tconv_scatter_wgrad); returns None when the shape / workspace does not allow it (caller: conv_bwd_weight)."""
+    lib = _lib.load()
+    need = int(lib.ali_tconv_scatter_wgrad_ws(B, P, Q, K, R, S, stride))
+    ws = workspace(big.device)
+    if need == 0 or ws.numel() < need:
+        return None
+
+    def go():
+        _lib.check(lib.ali_tconv_scatter_wgrad(_chk(big, "big"), _ptr(small), sstride, _ptr(dw), s_k, s_tap, B, P, Q, K, H,
+                                               W, R, S, stride, pad, c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                   "ali_tconv_scatter_wgrad")
+    _launch("tconv_scatter_wgrad", (2.0 * B * P * Q * K * R * S, 4.0 * B * (P * Q * K + H * W), _NO_SHAPE), go)
+    return dw
+
+
 def spect_post(y, B, T, F, out, mean=None, std=None, clip_k=3.0):
     lib = _lib.load()
     _lib.check(lib.ali_spect_post(_chk(y, "y"), B, T, F, _opt(mean, "mean"), _opt(std, "std"), float(clip_k),

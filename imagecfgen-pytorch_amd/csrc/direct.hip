@@ -625,6 +625,107 @@ __global__ __launch_bounds__(64 * NW) void tconv1_wgrad_mfma_kernel(const T1Desc
   }
 }
 
+// Weight gradient of a STRIDED transposed convolution to one channel (the Generator tails of the spectrogram stacks,
+// ConvTranspose2d(64 -> 1, 5, stride 2); audio_mnist.py:243):  dw[k][r*S+s] = sum_{b,p,q} big[b,p,q,k] * small[b, p*st - pad + r,
+// q*st - pad + s].  As a GEMM it has ONE gathered channel (1/32 of a tile: 1.25 ms per ESRF launch for 0.25 ms of
+// reading big once).  Same contraction over pixels as tconv1_wgrad_mfma_kernel -- one 16-byte load per lane per 4 pixels
+// is the A operand of four channel groups, v_mfma_f32_16x16x4_f32 -- but a block owns a BAND of big rows of one image
+// (the maps are 64^2 ... 256^2 x 64 channels: an image does not fit a block) and keeps the zero-padded rows of the small
+// map that the band reaches in LDS.  One slab per block, folded by t1_reduce_kernel in block order.
+struct TSWDesc {
+  const float* big; const float* small; float* part;
+  int B, P, Q, H, W, R, S, pad, stride, sstride, RB, bands;
+};
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void tconvs_wgrad_mfma_kernel(const TSWDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int K = 64;
+  const int st = d.stride;
+  const int SW = (d.Q - 1) * st + d.S;                    // band image: entry (i, j) = small[p0 * st - pad + i][j - pad]
+  const int SH = (d.RB - 1) * st + d.R;
+  float* simg = smem;                                     // [SH][SW]
+  float* red = smem;                                      // [NW][4][NT][64][4] fold scratch (the band image is dead by then)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int T = d.R * d.S;
+  const int b = blockIdx.x / d.bands, band = blockIdx.x - b * d.bands;
+  const int p0 = band * d.RB;
+  const int rows = min(d.RB, d.P - p0);
+  const int npix = rows * d.Q;
+  int toff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tap = nt * 16 + m;
+    const int tp = tap < T ? tap : 0;
+    toff[nt] = (tp / d.S) * SW + (tp % d.S);
+  }
+  f32x4v acc[4][NT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[e][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int i = t; i < SH * SW; i += 64 * NW) {
+    const int sr = i / SW, sc = i - sr * SW;
+    const int ih = p0 * st - d.pad + sr, iw = sc - d.pad;
+    float v = 0.f;
+    if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+      v = d.small[((long long)(b * d.H + ih) * d.W + iw) * d.sstride];
+    simg[i] = v;
+  }
+  __syncthreads();
+  const float rQ = 1.0f / (float)d.Q;
+  const int nstep = (npix + 3) >> 2;
+  constexpr int DEPTH = 8;
+  const float* src = d.big + ((long long)(b * d.P + p0) * d.Q) * K + 4 * m;
+  auto load_step = [&](int s4) -> f32x4v {
+    const int pix = s4 * 4 + kq;
+    if (s4 < nstep && pix < npix) return *reinterpret_cast<const f32x4v*>(src + (long long)pix * K);
+    return f32x4v{0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4v a[DEPTH];
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) a[u] = load_step(wave + u * NW);
+  for (int s0 = wave; s0 < nstep; s0 += DEPTH * NW) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const int s4 = s0 + u * NW;
+      const f32x4v av = a[u];
+      a[u] = load_step(s4 + DEPTH * NW);
+      if (s4 < nstep) {
+        int pix = s4 * 4 + kq;
+        if (pix >= npix) pix = npix - 1;                       // (its A values are zero)
+        int p = (int)((float)pix * rQ);
+        int q = pix - p * d.Q;
+        if (q < 0) { --p; q += d.Q; } else if (q >= d.Q) { ++p; q -= d.Q; }
+        const float* sp = simg + (p * SW + q) * st;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float bv = sp[toff[nt]];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[e][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv, acc[e][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // fold the waves in a fixed order: acc[e][nt][i] = dw[channel 4 * (4 kq + i) + e][tap 16 nt + m]
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      *reinterpret_cast<f32x4v*>(red + (((wave * 4 + e) * NT + nt) * 64 + lane) * 4) = acc[e][nt];
+  __syncthreads();
+  float* part = d.part + (long long)blockIdx.x * (K * T);
+  for (int o = t; o < 4 * NT * 64 * 4; o += 64 * NW) {
+    const int i = o & 3, l = (o >> 2) & 63, nt = (o >> 8) % NT, e = (o >> 8) / NT;
+    float v = 0.f;
+    for (int w = 0; w < NW; ++w) v += red[(((w * 4 + e) * NT + nt) * 64 + l) * 4 + i];
+    const int ch = 4 * (4 * (l >> 4) + i) + e, tap = nt * 16 + (l & 15);
+    if (tap < T) part[ch * T + tap] = v;
+  }
+}
+
 // out[c*s_c + k*s_k + tap*s_tap] = sum_b part[b][(c*K + k)*T + tap]   (one wave per output, fixed order)
 __global__ void t1_reduce_kernel(const float* __restrict__ part, int nblk, int K, int T, int NC, float* __restrict__ out,
                                  long long s_k, long long s_tap, long long s_c) {
@@ -734,6 +835,57 @@ extern "C" int ali_tconv_scatter(const float* x, const float* w_nc, const float*
   else TSC(4);
 #undef TSC
   return check_launch("tconv_scatter_kernel");
+}
+
+// (see tconvs_wgrad_mfma_kernel) returns the workspace bytes the launch needs, 0 when the shape is not served
+extern "C" int64_t ali_tconv_scatter_wgrad_ws(int32_t B, int32_t P, int32_t Q, int32_t K, int32_t R, int32_t S,
+                                              int32_t stride) {
+  if (K != 64 || R < 1 || S < 1 || R * S > 32 || stride < 1 || stride > 4 || B <= 0 || P <= 0 || Q <= 0 ||
+      tuning().no_t1_mfma != 0) return 0;
+  int rb = 8;
+  auto lds = [&](int r) {
+    const long long img = (((long long)((r - 1) * stride + R) * ((Q - 1) * stride + S)) + 3) & ~3LL;
+    return (size_t)std::max(img, 4LL * 4 * ((R * S + 15) / 16) * 64 * 4) * sizeof(float);
+  };
+  while (rb > 1 && lds(rb) > 64 * 1024) rb >>= 1;
+  if (lds(rb) > 64 * 1024) return 0;
+  const long long nblk = (long long)B * ((P + rb - 1) / rb);
+  if (nblk > (1 << 20)) return 0;
+  return (int64_t)nblk * K * R * S * (int64_t)sizeof(float) + (int64_t)kWsReserved;   // (incl. the reserved head)
+}
+
+extern "C" int ali_tconv_scatter_wgrad(const float* big, const float* small, int32_t sstride, float* dw, int64_t s_k,
+                                       int64_t s_tap, int32_t B, int32_t P, int32_t Q, int32_t K, int32_t H, int32_t W,
+                                       int32_t R, int32_t S, int32_t stride, int32_t pad, void* ws, size_t ws_bytes,
+                                       ali_stream_t stream) {
+  int64_t need = ali_tconv_scatter_wgrad_ws(B, P, Q, K, R, S, stride);
+  if (need > 0) need -= (int64_t)kWsReserved;
+  if (!big || !small || !dw || sstride < 1 || H <= 0 || W <= 0 || pad < 0 || need <= 0) {
+    set_error("ali_tconv_scatter_wgrad: bad argument / unsupported shape (ali_tconv_scatter_wgrad_ws)");
+    return ALI_ERR_BAD_ARG;
+  }
+  ws = ws_payload(ws);                       // (the head of every workspace holds the GEMM kernels' arrival counters)
+  ws_bytes = ws_payload_bytes(ws_bytes);
+  if (!ws || ws_bytes < (size_t)need) { set_error("ali_tconv_scatter_wgrad: workspace too small"); return ALI_ERR_WORKSPACE; }
+  const int T = R * S;
+  int rb = 8;
+  const int mnt = (T + 15) / 16;
+  auto lds = [&](int r) {
+    const long long img = (((long long)((r - 1) * stride + R) * ((Q - 1) * stride + S)) + 3) & ~3LL;
+    return (size_t)std::max(img, 4LL * 4 * mnt * 64 * 4) * sizeof(float);
+  };
+  while (rb > 1 && lds(rb) > 64 * 1024) rb >>= 1;
+  TSWDesc d = {};
+  d.big = big; d.small = small; d.part = reinterpret_cast<float*>(ws);
+  d.B = B; d.P = P; d.Q = Q; d.H = H; d.W = W; d.R = R; d.S = S; d.pad = pad; d.stride = stride; d.sstride = sstride;
+  d.RB = rb; d.bands = (P + rb - 1) / rb;
+  const int nblk = B * d.bands;
+  hipStream_t st = (hipStream_t)stream;
+  if (mnt == 1) hipLaunchKernelGGL((tconvs_wgrad_mfma_kernel<1, 4>), dim3(nblk), dim3(256), lds(rb), st, d);
+  else hipLaunchKernelGGL((tconvs_wgrad_mfma_kernel<2, 4>), dim3(nblk), dim3(256), lds(rb), st, d);
+  hipLaunchKernelGGL(t1_reduce_kernel, dim3(K * T), dim3(64), 0, st, d.part, nblk, K, T, 1, dw, (long long)s_k,
+                     (long long)s_tap, 0LL);
+  return check_launch("tconvs_wgrad_mfma");
 }
 
 extern "C" int ali_tconv1_dgrad(const float* small, int32_t sstride, const float* w_tk, const float* dact_y,

@@ -406,6 +406,15 @@ int ali_tconv_scatter(const float* x, const float* w_nc, const float* bias, floa
                       int32_t C, int32_t Hout, int32_t Wout, int32_t NC, int32_t ostride, int32_t R, int32_t S,
                       int32_t stride, int32_t pad, int32_t act, float slope, ali_stream_t stream);
 
+/* Weight gradient of that transposed convolution for ONE output channel: dw[k*s_k + (r*S+s)*s_tap] = sum_{b,p,q}
+ * big[b,p,q,k] * small[(b, p*stride - pad + r, q*stride - pad + s) * sstride], big = its 64-channel input [B,P,Q,64], small
+ * = the gradient of its [B,H,W] output (element stride sstride).  One launch + a slab fold; ali_tconv_scatter_wgrad_ws
+ * returns the workspace bytes it needs, 0 when the shape is not served (then: ali_conv_bwd_weight). */
+int64_t ali_tconv_scatter_wgrad_ws(int32_t B, int32_t P, int32_t Q, int32_t K, int32_t R, int32_t S, int32_t stride);
+int ali_tconv_scatter_wgrad(const float* big, const float* small, int32_t sstride, float* dw, int64_t s_k, int64_t s_tap,
+                            int32_t B, int32_t P, int32_t Q, int32_t K, int32_t H, int32_t W, int32_t R, int32_t S,
+                            int32_t stride, int32_t pad, void* ws, size_t ws_bytes, ali_stream_t stream);
+
 /* Tail of the spectrogram front-end (the step in front of the path): torchaudio.transforms.Spectrogram
  * (power 2) + (. + 1e-6).log() and, optionally, spect_to_img (audio_mnist.py:116,347-363 and copies).  `y` holds, per
  * frame (b,t), the windowed DFT as produced by a 1x1 ali_conv_fwd with the [2F x win] cos|sin matrix: re[f] = y[f],

@@ -326,6 +326,32 @@ def test_fused_scatter_transposed_conv(B, H, W, Co, stride, pad, opad, R, act):
         assert not ops.tconv_scatter_ok(Ci, Co, R, R, stride)
 
 
+@pytest.mark.parametrize("B,H,W,stride,pad,opad,R", [(3, 20, 28, 2, 2, 1, 5), (2, 37, 19, 2, 1, 1, 5), (2, 64, 64, 2, 2, 1, 5),
+                                                     (2, 12, 40, 1, 1, 0, 3), (1, 9, 31, 3, 0, 2, 4)])
+def test_strided_one_channel_transposed_conv_weight_gradient(B, H, W, stride, pad, opad, R):
+    """ali_tconv_scatter_wgrad: dW of ConvTranspose2d(64 -> 1, R, stride) as a contraction over pixels on the matrix cores
+    (bands of the 64-channel input, the output gradient's rows in LDS) vs torch autograd, contiguous and pack-order dW."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(H * 5 + W + R)
+    Ci = 64
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Ci, 1, R, R, generator=g, requires_grad=True)
+    y = F.conv_transpose2d(x, w, None, stride=stride, padding=pad, output_padding=opad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    xh, gyh = nhwc(x).cuda(), nhwc(gy).cuda()
+    dw = torch.full((Ci, 1, R, R), float("nan"), device="cuda")
+    assert ops.tconv_scatter_wgrad(xh, gyh, 1, dw, dw.stride(0), dw.stride(3), B, H, W, Ci, Ho, Wo, R, R, stride, pad) is dw
+    close(dw, w.grad, what="strided one-channel convT weight gradient")
+    buf = torch.full((R * R, Ci), float("nan"), device="cuda")          # [taps][Ci]: the forward pack's order
+    dwp = torch.as_strided(buf, (Ci, 1, R, R), (1, R * R * Ci, R * Ci, Ci))
+    ops.tconv_scatter_wgrad(xh, gyh, 1, dwp, dwp.stride(0), dwp.stride(3), B, H, W, Ci, Ho, Wo, R, R, stride, pad)
+    assert torch.equal(dwp.contiguous(), dw)
+    # its slabs live behind the workspace's reserved head (the GEMM kernels' arrival counters, left at zero)
+    assert not ops.workspace(torch.device("cuda"))[:4096].any().item()
+
+
 @pytest.mark.parametrize("n_fft,win,hop,pad,L", [(255, 128, None, 96, 8000), (511, 128, 24, 64, 2900),
                                                    (1023, 256, 79, 200, 9000)])
 def test_spectrogram_front_end_vs_torch_stft(n_fft, win, hop, pad, L):
