@@ -1366,7 +1366,6 @@ extern "C" size_t ali_conv_workspace_bytes(const AliConvGeom* g, int32_t which) 
 // statistics: one slot per image).
 constexpr int CF_C = 8, CF_K = 32;
 constexpr int CF_PIXLD = 12;   // LDS pixel stride (dwords): 12 mod 64 -> the image's ds_read_b128 are conflict-free
-constexpr int CF_WLD = 200;    // weight rows as packed (read once per wave: conflicts do not matter); 64,256 B of LDS in all
 
 struct CFDesc {
   const float* in; const float* w; float* out;
@@ -1381,8 +1380,10 @@ template <int TAPS, int CL = 8>
 __global__ __launch_bounds__(256) void conv_first_kernel(const CFDesc d) {
   extern __shared__ __attribute__((aligned(16))) float cf_smem[];
   float* img = cf_smem;                                   // [H*W][CF_PIXLD]
-  float* wl = cf_smem + d.H * d.W * CF_PIXLD;             // [32][CF_WLD]
-  float* red = wl + CF_K * CF_WLD;                        // [2][4][32] BatchNorm partials of the 4 waves
+  float* red = cf_smem + d.H * d.W * CF_PIXLD;            // [2][4][32] BatchNorm partials of the 4 waves
+  // (the 32 x TAPS x 8 weights go straight from memory -- 25.6 KB, L2-resident -- into every lane's registers: staging
+  // them in LDS first cost 26 of the block's 64 KB, i.e. two resident blocks per CU instead of four, and a barrier)
+  const float* wl = d.w;                                  // packed [32][TAPS][8]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int b = blockIdx.x;
   const int HW = d.H * d.W, PQ = d.P * d.Q;
@@ -1391,13 +1392,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const CFDesc d) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
     *reinterpret_cast<f32x4*>(img + (i >> 1) * CF_PIXLD + (i & 1) * 4) = v;
   }
-  for (int i = t; i < CF_K * TAPS * 2; i += 256) {        // packed weights [32][TAPS][8]
-    const int n = i / (TAPS * 2), rem = i - n * (TAPS * 2);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(d.w + (long long)n * TAPS * CF_C + rem * 4);
-    *reinterpret_cast<f32x4*>(wl + n * CF_WLD + rem * 4) = v;
-  }
-  __syncthreads();
   const int lrow = lane & 31, lh = lane >> 5;
+  constexpr int CF_WLD = TAPS * CF_C;                      // row pitch of the packed weights
   constexpr int KL = TAPS * CL, NS = (KL + 1) / 2;         // live reduction length, MFMA steps (k = 2*step + lh)
   f32x4 wf[CL == 8 ? TAPS : 1];                            // CL == 8: B fragments of every tap (row n = lane&31, channels 4*lh..+3)
   float wb[CL == 8 ? 1 : NS];                              // CL < 8: B value and A offset of this lane's k of every step
@@ -1417,6 +1413,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const CFDesc d) {
       aoff[st] = (r * d.W + sx) * CF_PIXLD + c;
     }
   }
+  __syncthreads();                                         // the image is in LDS
   const AliEpilogue& ep = d.ep;
   const float bias = ep.bias ? ep.bias[lrow] : 0.f;
   const float smask = (ep.bn_part && ep.bn_stat_mask) ? ep.bn_stat_mask[(long long)b * ep.bn_mask_ld + lrow] : 1.f;
@@ -1492,7 +1489,7 @@ static int conv_first_launch(const AliConvGeom* g, const float* x, const float* 
   d.in = x; d.w = w; d.out = y;
   if (ep) d.ep = *ep;
   d.B = g->B; d.H = g->H; d.W = g->W; d.P = g->P; d.Q = g->Q; d.R = g->R; d.S = g->S;
-  const size_t lds = ((size_t)g->H * g->W * CF_PIXLD + (size_t)CF_K * CF_WLD + 256) * sizeof(float);
+  const size_t lds = ((size_t)g->H * g->W * CF_PIXLD + 256) * sizeof(float);
   const int live = ep ? ep->in_ch_live : 0;
   if (g->R == 5 && live == 5) hipLaunchKernelGGL((conv_first_kernel<25, 5>), dim3(g->B), dim3(256), lds, stream, d);
   else if (g->R == 5) hipLaunchKernelGGL((conv_first_kernel<25>), dim3(g->B), dim3(256), lds, stream, d);
