@@ -5,6 +5,7 @@
 // in include/ali_hip.h.  All reductions are deterministic (fixed partial slabs,
 // fixed summation order; no float atomics).
 #include "ali_common.h"
+#include <algorithm>
 #include <string.h>
 
 namespace ali {
@@ -889,52 +890,63 @@ __global__ void bce_logits_pair_kernel(const float* __restrict__ logit, int B, f
 }
 
 struct EmbPtrs { const float* t[8]; };
-__global__ void assemble_planes_kernel(const float* __restrict__ X, const int* __restrict__ idx, EmbPtrs emb, int n_emb,
-                                       const float* __restrict__ cont, int n_cont, float* __restrict__ out, int B,
-                                       int H, int W, int Cpad, const float* __restrict__ mask, int mask_ld) {
-  const long long npix = (long long)B * H * W;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long step = (long long)gridDim.x * blockDim.x;
-  const bool small = npix < (1LL << 31);       // 32-bit index arithmetic (64-bit divisions cost hundreds of cycles each)
-  for (; i < npix; i += step) {
-    int w, h, b;
-    if (small) {
-      const unsigned iu = (unsigned)i, t2 = iu / (unsigned)W;
-      w = (int)(iu - t2 * (unsigned)W);
-      b = (int)(t2 / (unsigned)H);
-      h = (int)(t2 - (unsigned)b * (unsigned)H);
-    } else {
-      w = (int)(i % W);
-      const long long t2 = i / W;
-      h = (int)(t2 % H);
-      b = (int)(t2 / H);
-    }
-    // nearest: src = floor(dst * 16 / size)  (torch 'nearest', probe-verified in SURVEY.md K8)
-    const int sh = (h * 16) / H, sw = (w * 16) / W;
-    float* o = out + i * Cpad;
-    if (Cpad == 8 || Cpad == 4) {        // 5 planes in 8 channels (MNIST), 2-4 in 4 (whale / ESRF): 16-byte stores per pixel
-      float v[8];
-      v[0] = X[i];
-      int c = 1;
-      for (int j = 0; j < n_emb; ++j, ++c) v[c] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + sh * 16 + sw]);
-      for (int j = 0; j < n_cont; ++j, ++c) v[c] = cont[b * n_cont + j];
-      for (; c < 8; ++c) v[c] = 0.f;
-      if (mask) {                        // the Dropout2d in front of the consuming conv, per (sample, channel)
+// One block = a run of pixels of ONE image (grid: chunks x B).  The embedding planes are 16 x 16 tables blown up to the
+// image size (nearest), so their tanh is taken once per block into LDS (256 values per table) instead of once per pixel
+// (512^2 maps: 1024x redundant, and with two 32-bit divisions per pixel on top the kernel was VALU bound: 1.6 TB/s).
+__global__ void __launch_bounds__(256)
+assemble_planes_kernel(const float* __restrict__ X, const int* __restrict__ idx, EmbPtrs emb, int n_emb,
+                       const float* __restrict__ cont, int n_cont, float* __restrict__ out, int B, int H, int W, int Cpad,
+                       const float* __restrict__ mask, int mask_ld, int chunk) {
+  __shared__ float tab[8][256];
+  const int t = threadIdx.x, b = blockIdx.y;
+  for (int j = 0; j < n_emb; ++j) tab[j][t] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + t]);
+  float cv[8], mk[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < Cpad) v[e] *= mask[(long long)b * mask_ld + e];
-      }
+  for (int j = 0; j < 8; ++j) {
+    cv[j] = j < n_cont ? cont[b * n_cont + j] : 0.f;
+    mk[j] = (mask && j < Cpad) ? mask[(long long)b * mask_ld + j] : 1.f;
+  }
+  __syncthreads();
+  const int HW = H * W;
+  const int p1 = min(HW, (int)(blockIdx.x + 1) * chunk);
+  const float* Xb = X + (long long)b * HW;
+  float* ob = out + (long long)b * HW * Cpad;
+  auto emit = [&](int p, int sh, int sw) {
+    float v[8];
+    v[0] = Xb[p];
+    int c = 1;
+    for (int j = 0; j < n_emb; ++j, ++c) v[c] = tab[j][sh * 16 + sw];
+    for (int j = 0; j < n_cont; ++j, ++c) v[c] = cv[j];
+    for (; c < 8; ++c) v[c] = 0.f;
+    float* o = ob + (long long)p * Cpad;
+    if (Cpad == 8 || Cpad == 4) {        // 5 planes in 8 channels (MNIST), 2-4 in 4 (whale / ESRF): 16-byte stores per pixel
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= mk[e];            // the Dropout2d in front of the consuming conv, per (sample, channel)
       *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
       if (Cpad == 8) *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      continue;
+    } else {
+      for (int e = 0; e < Cpad; ++e) o[e] = (e < 8 ? v[e] * mk[e] : 0.f);
     }
-    o[0] = X[i];
-    int c = 1;
-    for (int j = 0; j < n_emb; ++j, ++c) o[c] = tanhf(emb.t[j][idx[b * n_emb + j] * 256 + sh * 16 + sw]);
-    for (int j = 0; j < n_cont; ++j, ++c) o[c] = cont[b * n_cont + j];
-    for (; c < Cpad; ++c) o[c] = 0.f;
-    if (mask)
-      for (c = 0; c < Cpad; ++c) o[c] *= mask[(long long)b * mask_ld + c];
+  };
+  // nearest: src = floor(dst * 16 / size)  (torch 'nearest', probe-verified in SURVEY.md K8)
+  const int p0 = blockIdx.x * chunk;
+  if ((W & 255) == 0 && (chunk % W) == 0) {
+    // wide maps, a run = whole rows: a thread keeps its columns, the row index is uniform -- no division per pixel
+    // (three 32-bit divisions per pixel kept the kernel at 1.8 TB/s)
+    const int per = W >> 8, row0 = p0 / W, nrows = (p1 - p0) / W;
+    for (int k = 0; k < per; ++k) {
+      const int w = t + 256 * k;
+      const int sw = (int)((unsigned)(w * 16) / (unsigned)W);
+      for (int r = 0; r < nrows; ++r) {
+        const int h = row0 + r;
+        emit(h * W + w, (int)((unsigned)(h * 16) / (unsigned)H), sw);
+      }
+    }
+  } else {
+    for (int p = p0 + t; p < p1; p += 256) {
+      const int h = (int)((unsigned)p / (unsigned)W), w = p - h * W;
+      emit(p, (int)((unsigned)(h * 16) / (unsigned)H), (int)((unsigned)(w * 16) / (unsigned)W));
+    }
   }
 }
 
@@ -1487,14 +1499,21 @@ extern "C" int ali_assemble_planes(const float* X, const int32_t* idx, const flo
                                    const float* cont, int32_t n_cont, float* out, int32_t B, int32_t H, int32_t W,
                                    int32_t Cpad, const float* mask, int32_t mask_ld, ali_stream_t stream) {
   if (!X || !out || B <= 0 || H <= 0 || W <= 0 || n_emb < 0 || n_emb > 8 || n_cont < 0 || 1 + n_emb + n_cont > Cpad ||
+      1 + n_emb + n_cont > 8 ||
       (n_emb > 0 && (!idx || !emb_tables)) || (n_cont > 0 && !cont)) {
     set_error("ali_assemble_planes: bad argument");
     return ALI_ERR_BAD_ARG;
   }
   EmbPtrs e;
   for (int j = 0; j < 8; ++j) e.t[j] = j < n_emb ? emb_tables[j] : nullptr;
-  const long long npix = (long long)B * H * W;
-  hipLaunchKernelGGL(assemble_planes_kernel, dim3(ew_grid(npix)), dim3(kEwBlock), 0, ST(stream), X, idx, e, n_emb, cont, n_cont,
-                     out, B, H, W, Cpad, mask, mask_ld);
+  if (B > 65535 || (long long)H * W >= (1LL << 27)) { set_error("ali_assemble_planes: map too large"); return ALI_ERR_BAD_ARG; }
+  const int HW = H * W;
+  // >= ~2048 blocks on large maps, one block per image on small ones; a run is a multiple of 256 pixels
+  int chunks = (int)std::min<long long>((HW + 1023) / 1024, std::max<long long>(1, (2048 + B - 1) / B));
+  int chunk = (((HW + chunks - 1) / chunks) + 255) & ~255;
+  if ((W & 255) == 0) chunk = ((chunk + W - 1) / W) * W;          // whole rows (the kernel's division-free walk)
+  chunks = (HW + chunk - 1) / chunk;
+  hipLaunchKernelGGL(assemble_planes_kernel, dim3(chunks, B), dim3(256), 0, ST(stream), X, idx, e, n_emb, cont, n_cont,
+                     out, B, H, W, Cpad, mask, mask_ld, chunk);
   return check_launch("assemble_planes_kernel");
 }
