@@ -385,6 +385,55 @@ __global__ __launch_bounds__(256) void tconv1_dgrad_kernel(const T1Desc d) {
   }
 }
 
+// Band form (what the launcher uses when the zero-padded rows of the 1-channel map that a band of output rows reaches fit
+// 32 KB of LDS -- always on the small maps these kernels serve): a block owns RB output rows of ONE image, the taps come
+// from LDS (one ds_read_b32 per tap, the K/4 threads of a pixel read the same word) instead of 16-25 scalar memory loads
+// per 16-byte store -- the kernel issued 18 memory instructions per KB it wrote and three 64-bit divisions per item
+// (3.0 TB/s); now its memory instructions are the act' operand and the store, index arithmetic is 32-bit.
+template <int TAPS>
+__global__ __launch_bounds__(256) void tconv1_dgrad_band_kernel(const T1Desc d, int RB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int SW = d.Q + d.S - 1;                            // band image: entry (i, j) = small[p0 + i - pad][j - pad]
+  const int t = threadIdx.x;
+  const int K4 = d.K / 4;
+  const int k4 = t % K4;
+  f32x4 wr[TAPS];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) wr[tp] = *reinterpret_cast<const f32x4*>(d.w + tp * d.K + k4 * 4);
+  const int b = blockIdx.y, p0 = blockIdx.x * RB;
+  const int rows = min(RB, d.P - p0);
+  const int SH = rows + d.R - 1;
+  const float* sb = d.small + (long long)b * d.H * d.W * d.sstride;
+  for (int i = t; i < SH * SW; i += 256) {
+    const int sr = i / SW, sc = i - sr * SW;
+    const int ih = p0 + sr - d.pad, iw = sc - d.pad;
+    float v = 0.f;
+    if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) v = sb[(long long)(ih * d.W + iw) * d.sstride];
+    smem[i] = v;
+  }
+  __syncthreads();
+  const int ppt = 256 / K4;                               // pixels per pass of the block
+  const int npix = rows * d.Q;
+  const long long obase = ((long long)(b * d.P + p0) * d.Q) * d.K + k4 * 4;
+  for (int pix = t / K4; pix < npix; pix += ppt) {
+    const int p = pix / d.Q, q = pix - p * d.Q;
+    const float* sp = smem + p * SW + q;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const int r = tp / d.S, sx = tp - r * d.S;
+      a += sp[r * SW + sx] * wr[tp];
+    }
+    const long long o = obase + (long long)pix * d.K;
+    if (d.dact_y) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(d.dact_y + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= act_grad_from_output(y[e], d.dact, d.dslope);
+    }
+    *reinterpret_cast<f32x4*>(d.out + o) = a;
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient: partial [nblk][NC][K*T]
 // A block walks over (image, band of T1W_RB big rows) work items and keeps its sums in registers, so only
 // gridDim.x slabs have to be folded.  thread = (k, tap group g) owning taps g, g+G, ... for every small channel.
@@ -903,6 +952,24 @@ extern "C" int ali_tconv1_dgrad(const float* small, int32_t sstride, const float
   if (nb > 4096) nb = 4096;              // (one output per thread was measured slower: 75 vs 54 us, the tap preload dominates)
   if (256 % (K / 4) != 0) { set_error("ali_tconv1_dgrad: K/4 must divide 256"); return ALI_ERR_BAD_ARG; }
   const int T = R * S;
+  {
+    // band form: RB output rows per block so that >= ~2 blocks per CU exist, LDS <= 32 KB
+    int rbv = P;
+    while (rbv > 1 && (long long)B * ((P + rbv - 1) / rbv) < 2 * kNumCU) rbv = (rbv + 1) / 2;
+    const size_t lds = (size_t)(rbv + R - 1) * (Q + S - 1) * sizeof(float);
+    if (lds <= 32 * 1024 && B <= 65535 && tuning().no_t1_mfma == 0) {
+      dim3 grid((P + rbv - 1) / rbv, B);
+#define T1B(T_) hipLaunchKernelGGL(tconv1_dgrad_band_kernel<T_>, grid, dim3(256), lds, (hipStream_t)stream, d, rbv)
+      if (T == 16) T1B(16);
+      else if (T == 25) T1B(25);
+      else if (T == 9) T1B(9);
+      else if (T == 4) T1B(4);
+      else if (T == 1) T1B(1);
+      else { set_error("ali_tconv1_dgrad: unsupported kernel size %dx%d", R, S); return ALI_ERR_BAD_ARG; }
+#undef T1B
+      return check_launch("tconv1_dgrad_band_kernel");
+    }
+  }
 #define T1D(T_) hipLaunchKernelGGL(tconv1_dgrad_kernel<T_>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, d)
   if (T == 16) T1D(16);
   else if (T == 25) T1D(25);
