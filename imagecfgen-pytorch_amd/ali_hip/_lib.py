@@ -28,7 +28,7 @@ class AliEpilogue(Structure):
                 ("bn_mask_in", c_void_p), ("bn_mask_pre", c_void_p), ("mfma_f16", c_int32),
                 ("in16", c_void_p), ("w16", c_void_p), ("out16", c_void_p),
                 ("tile_order", c_void_p), ("tile_order_n", c_int32), ("in_ld", c_int32), ("out_ld", c_int32),
-                ("in_ch_live", c_int32), ("bn_slots", c_int32)]
+                ("in_ch_live", c_int32), ("bn_slots", c_int32), ("dact_y16", c_void_p)]
 
 
 class AliWgradFold(Structure):

@@ -49,6 +49,7 @@ def _opt(t, name="tensor"):
 
 
 _PRECISION = {"f16": False}
+_DACT16 = {"on": __import__("os").environ.get("ALI_NO_DACT16", "0") in ("", "0")}   # (A/B switch of AliEpilogue.dact_y16)
 
 
 class precision:
@@ -88,6 +89,10 @@ def epilogue(bias=None, act=ACT_NONE, slope=0.0, mask=None, dact_y=None, dact=AC
     ep.mask_ld = mask.shape[1] if mask is not None else 0
     ep.dact_y = _opt(dact_y, "dact_y")
     ep.dact, ep.dslope = dact, dslope
+    tw = getattr(dact_y, "_ali16", None) if (dact_y is not None and _PRECISION["f16"] and _DACT16["on"]) else None
+    if tw is not None and tw.shape == dact_y.shape and tw.is_contiguous():
+        ep.dact_y16 = c_void_p(tw.data_ptr())     # act' from the fp16 twin: half the bytes of the epilogue's read
+        ep.refs["dact_y16"] = tw
     ep.mfma_f16 = int(_PRECISION["f16"])
     if bn_fwd is not None:
         part, groups, smask = bn_fwd[:3]

@@ -816,6 +816,7 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
     float bs0[TN], bs1[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bs0[j] = bs1[j] = 0.f;
+    const _Float16* dact16 = (HAS_DACT && d.f16) ? reinterpret_cast<const _Float16*>(ep.dact_y16) : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -841,8 +842,13 @@ __device__ __forceinline__ void gconv_body(const GDesc& d, const int bx_, const 
             for (int q = 0; q < 8; ++q) mk[q] = ep.mask[(long long)rimg[q] * ep.mask_ld + nc];
           }
           if (HAS_DACT) {
+            if (dact16) {                  // (fp16 path: the twin of the previous layer's output, half the bytes)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dy[q] = ep.dact_y[(roff[q] < 0 ? 0 : roff[q]) + nc];
+              for (int q = 0; q < 8; ++q) dy[q] = (float)dact16[(roff[q] < 0 ? 0 : roff[q]) + nc];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) dy[q] = ep.dact_y[(roff[q] < 0 ? 0 : roff[q]) + nc];
+            }
           }
           if (BNM == 1) {
 #pragma unroll

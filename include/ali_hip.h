@@ -118,6 +118,11 @@ typedef struct {
    * whose M-tile count differs (tuning reloaded in between, other precision) fails with ALI_ERR_BAD_ARG instead of
    * writing out of bounds.  0 = unchecked. */
   int32_t bn_slots;
+  /* mfma_f16 launches: the fp16 twin of dact_y (same layout), or NULL.  When given, act' is evaluated on it instead of
+   * on dact_y -- the sign / value of the previous layer's output as the next layer's GEMM saw it -- and the launch reads
+   * 2 instead of 4 bytes per output element (the data gradients of the first layers are bound by exactly these bytes).
+   * dact_y must still be passed (it selects the epilogue). */
+  const void* dact_y16;
 } AliEpilogue;
 
 /* A weight-gradient launch that splits the pixel range writes S partial results ("slabs") into its workspace and

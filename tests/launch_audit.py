@@ -94,7 +94,8 @@ class LaunchAudit:
         if refs.get("mask") is not None:
             ref = ref * refs["mask"].detach().cpu()[:, :n_out].reshape(oshape[0], 1, 1, n_out)
         if refs.get("dact_y") is not None:
-            yprev = refs["dact_y"].detach().reshape(oshape).cpu()
+            src = refs["dact_y16"].float() if refs.get("dact_y16") is not None else refs["dact_y"]   # (fp16 path: the twin)
+            yprev = src.detach().reshape(oshape).cpu()
             ref = ref * _dact(yprev, int(ep.dact), float(ep.dslope))
         got = out.detach().reshape(oshape).cpu()
         self._cmp(got, ref, f"{kind} {(B, H, W, C, P, Q, K, R, stride, pad)}{' f16' if f16 else ''}")
